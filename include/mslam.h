@@ -1,0 +1,308 @@
+/*
+ * mslam.h -- C ABI of libmslam_hip.so: the MI355X (gfx950) implementation of the
+ * per-frame tracking/mapping hot path of a monocular ORB SLAM pipeline.
+ *
+ * Every entry point states which interface of the reference (eastgeneral2007/
+ * Monocular_SLAM, paths relative to its root) it stands in for.  The reference has no
+ * FFI: its only plug-in surface is the C++ virtual `ProcessingNode::process(DataManager&,
+ * int)` (src/ProcessingNode.h:16-32), and all arithmetic of this path sits behind the
+ * OpenCV 2.4.13 / g2o calls made from the three stage classes.  The entry points below
+ * are exactly those call sites, flattened to plain pointers and sizes.
+ *
+ * Conventions
+ *  - every function returns an int status: MSLAM_OK (0) or a negative mslam_status.
+ *  - the caller owns every buffer; the library owns only the opaque context, its HIP
+ *    stream and its device scratch.  One context per GPU; a context is not thread-safe;
+ *    distinct contexts are independent.
+ *  - functions without a suffix take HOST pointers, copy in, run the device path, copy
+ *    out and synchronise.  `_dev` functions take DEVICE pointers (hipMalloc memory on the
+ *    context's device), enqueue on the context's stream and return without synchronising
+ *    (use mslam_sync).  There is no CPU fallback anywhere in this library: without a
+ *    usable gfx950 device mslam_create fails with MSLAM_ERR_NO_DEVICE.
+ *  - "batch" = independent frames/problems processed by one launch sequence.
+ */
+#ifndef MSLAM_H
+#define MSLAM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    MSLAM_OK = 0,
+    MSLAM_ERR_INVALID = -1,     /* bad argument (null pointer, size out of range) */
+    MSLAM_ERR_HIP = -2,         /* a HIP runtime call failed (see mslam_last_hip_error) */
+    MSLAM_ERR_CAPACITY = -3,    /* result does not fit the capacity given at create/call */
+    MSLAM_ERR_TOO_FEW = -4,     /* too few rows/points (e.g. kNN-2 with < 2 train rows:
+                                   the reference indexes raw_matches[i][1] unguarded,
+                                   src/CameraPoseEstimator.cpp:209) */
+    MSLAM_ERR_NO_DEVICE = -5,   /* no usable gfx950 device */
+    MSLAM_ERR_DEGENERATE = -6   /* no valid model found (all hypotheses degenerate) */
+} mslam_status;
+
+typedef struct mslam_ctx mslam_ctx;
+
+/* ---- context ---------------------------------------------------------------------- */
+
+/* device: HIP ordinal.  max_w/max_h: largest frame.  max_kpts: capacity of a per-frame
+ * keypoint list (>= nfeatures + room for response ties, see mslam_orb_extract).
+ * batch: frames per launch sequence (>= 1). */
+int mslam_create(mslam_ctx** out, int device, int max_w, int max_h, int max_kpts, int batch);
+void mslam_destroy(mslam_ctx* ctx);
+int mslam_sync(mslam_ctx* ctx);
+/* the context's hipStream_t (as void*), for callers that time with HIP events */
+void* mslam_stream(mslam_ctx* ctx);
+const char* mslam_strerror(int status);
+/* text of the last failing HIP call on this context ("" if none) */
+const char* mslam_last_hip_error(mslam_ctx* ctx);
+/* ABI version of this header: major*1000 + minor */
+int mslam_abi_version(void);
+
+/* device memory helpers so that FFI callers without a HIP binding can stage buffers */
+int mslam_dev_alloc(mslam_ctx* ctx, void** dptr, uint64_t bytes);
+int mslam_dev_free(mslam_ctx* ctx, void* dptr);
+int mslam_memcpy_h2d(mslam_ctx* ctx, void* dst_dev, const void* src_host, uint64_t bytes);
+int mslam_memcpy_d2h(mslam_ctx* ctx, void* dst_host, const void* src_dev, uint64_t bytes);
+
+/* HIP-event timing on the context's stream (so FFI callers can bracket launches) */
+int mslam_event_create(mslam_ctx* ctx, void** ev);
+int mslam_event_destroy(mslam_ctx* ctx, void* ev);
+int mslam_event_record(mslam_ctx* ctx, void* ev);
+int mslam_event_elapsed_ms(mslam_ctx* ctx, void* ev_start, void* ev_stop, float* ms); /* syncs on stop */
+
+/* ---- R1-R6: ORB detect + describe --------------------------------------------------
+ * Stands in for `detector.detect(frameBuffer, keypoints)` + `extractor.compute(
+ * frameBuffer, keypoints, descriptor)` of FeatureExtractor::process
+ * (src/FeatureExtractor.cpp:17,19), i.e. cv::ORB (OpenCV 2.4.13) with the parameters of
+ * the default-constructed OrbFeatureDetector/OrbDescriptorExtractor
+ * (src/FeatureExtractor.h:23-24). */
+typedef struct {
+    int nfeatures;       /* 500 */
+    float scale_factor;  /* 1.2f */
+    int nlevels;         /* 8  (1..MSLAM_MAX_LEVELS) */
+    int edge_threshold;  /* 31 */
+    int first_level;     /* 0 (only 0 supported) */
+    int wta_k;           /* 2 (only 2 supported) */
+    int score_type;      /* 0 = HARRIS_SCORE, 1 = FAST_SCORE */
+    int patch_size;      /* 31 (only 31 supported: the learned pattern) */
+    int fast_threshold;  /* 20 (hard-wired in OpenCV 2.4.13's ORB) */
+} mslam_orb_params;
+#define MSLAM_MAX_LEVELS 16
+void mslam_orb_default_params(mslam_orb_params* p);
+
+/* cv::KeyPoint fields the reference reads (pt, size) plus the ones ORB fills */
+typedef struct {
+    float x, y;      /* level-0 pixel coordinates */
+    float size;      /* 31 * scale_factor^octave */
+    float angle;     /* degrees, [0,360) */
+    float response;  /* Harris (or FAST) score */
+    int32_t octave;  /* pyramid level */
+} mslam_keypoint;    /* 24 bytes */
+
+/* One frame.  img: h rows of `stride` bytes, `channels` in {1,3,4} interleaved (BGR[A],
+ * as loaded by imread(..., CV_LOAD_IMAGE_UNCHANGED), src/FrameLoader.cpp:62).
+ * kps/desc: capacity `cap` keypoints / cap*32 bytes.  Keypoints come out level-major and
+ * row-major (y, then x) inside a level; the kept set is OpenCV's retainBest set (all
+ * keypoints whose response is >= the n-th best), so n_out may exceed nfeatures on ties;
+ * MSLAM_ERR_CAPACITY if it exceeds cap or the context's max_kpts. */
+int mslam_orb_extract(mslam_ctx* ctx, const uint8_t* img, int w, int h, int stride, int channels,
+                      const mslam_orb_params* params,
+                      mslam_keypoint* kps, uint8_t* desc, int cap, int* n_out);
+
+/* Batched, device-resident.  imgs: B frames, frame b at imgs + b*frame_stride.
+ * kps: B*cap keypoints, desc: B*cap*32 bytes, n_out: B int32 (device).  B <= ctx batch.
+ * status_dev (optional, B int32, device): per-frame MSLAM_OK / MSLAM_ERR_CAPACITY. */
+int mslam_orb_extract_batch_dev(mslam_ctx* ctx, const uint8_t* imgs, int B, int w, int h, int stride,
+                                int64_t frame_stride, int channels, const mslam_orb_params* params,
+                                mslam_keypoint* kps, uint8_t* desc, int cap, int32_t* n_out,
+                                int32_t* status_dev);
+
+/* Test hooks: intermediate products of the last single-frame mslam_orb_extract on this
+ * context, so that parity can be checked stage by stage (pyramid level and its 7x7
+ * Gaussian-blurred twin, tightly packed level_w*level_h bytes). */
+int mslam_orb_debug_level(mslam_ctx* ctx, int level, int blurred, uint8_t* out, int* level_w, int* level_h);
+
+/* ---- R7: brute-force Hamming kNN-2 + ratio test ------------------------------------
+ * Stands in for `BFMatcher(NORM_HAMMING,false).knnMatch(d1, d2, raw, 2)` and the ratio
+ * loop of matchFeatures (src/CameraPoseEstimator.cpp:200-213).
+ * q: nq x 32 bytes, t: nt x 32 bytes.  idx/dist: nq x 2 (best, second).  Ties go to the
+ * lower train index.  nt < 2 -> MSLAM_ERR_TOO_FEW. */
+int mslam_match_knn2(mslam_ctx* ctx, const uint8_t* q, int nq, const uint8_t* t, int nt,
+                     int32_t* idx, int32_t* dist);
+/* keep query i iff (float)d0 < (float)d1 * ratio; output in query order */
+int mslam_ratio_filter(const int32_t* idx, const int32_t* dist, int nq, float ratio,
+                       int32_t* query_idx, int32_t* train_idx, float* d, int* n_out);
+
+/* Batched, device-resident: problem b matches q + b*cap*32 (nq[b] rows) against
+ * t + b*cap*32 (nt[b] rows); nq/nt are device int32[B].  idx/dist: B*cap*2.
+ * If ratio > 0 the ratio test is applied on device and the surviving matches are
+ * written compacted in query order to m_query/m_train (B*cap int32) and m_dist (B*cap
+ * float) with the count in m_count[b]; pass ratio <= 0 and NULLs to skip.
+ * A problem with nt[b] < 2 yields m_count[b] = 0 and idx = -1. */
+int mslam_match_knn2_batch_dev(mslam_ctx* ctx, const uint8_t* q, const int32_t* nq,
+                               const uint8_t* t, const int32_t* nt, int cap, int B,
+                               int32_t* idx, int32_t* dist, float ratio,
+                               int32_t* m_query, int32_t* m_train, float* m_dist, int32_t* m_count);
+
+/* ---- R8/R9: eight-point fundamental-matrix RANSAC -----------------------------------
+ * Stands in for computeFundamentalMatrix (src/CameraPoseEstimator.cpp:545-586:
+ * findFundamentalMat(CV_FM_RANSAC, 3.0, 0.85) + CV_FM_8POINT refit on the inliers) and
+ * is the literal restatement of the in-tree eight-point RANSAC computeFundamentalMatrix2
+ * / fundamentalMatrix / getInlier / getRandomSample (:596-786) with its index-width and
+ * second-image bugs fixed.  The sample table is an explicit input (H x 8 indices into
+ * the M pairs) so that the scored hypotheses are reproducible. */
+typedef struct {
+    int metric;         /* 0: Sampson distance on coordinates divided by max coordinate,
+                              as getInlier (:715-763), inlier iff d < threshold (0.1)
+                           1: max of the two squared point-to-epipolar-line distances in
+                              pixels, as OpenCV's RANSAC, inlier iff err <= threshold^2 (3.0) */
+    double threshold;
+    double confidence;  /* in (0,1): OpenCV-style adaptive stop emulated over the ordered
+                           hypotheses; <= 0 or >= 1: every hypothesis counts */
+    int refit;          /* 0: none (F of the best hypothesis)
+                           1: un-normalised refit on all inliers (fundamentalMatrix, :665)
+                           2: Hartley-normalised 8-point on the inliers (CV_FM_8POINT, :585) */
+} mslam_fmat_params;
+void mslam_fmat_default_params(mslam_fmat_params* p); /* metric 1, 3.0, 0.85, refit 2 */
+
+/* x1,x2: M x 2 doubles (pixel coordinates in image 1 / image 2); samples: H x 8.
+ * F: row-major 3x3 with x2^T F x1 = 0.  status: M bytes (1 = inlier of the best
+ * hypothesis).  inlier_counts (optional): H.  best_h: winning hypothesis (max count,
+ * lowest index on ties, within the confidence-limited prefix). */
+int mslam_fmat_ransac8(mslam_ctx* ctx, const double* x1, const double* x2, int M,
+                       const int32_t* samples, int H, const mslam_fmat_params* params,
+                       double F[9], uint8_t* status, int32_t* inlier_counts, int* best_h,
+                       int* n_inliers);
+/* Batched, device-resident: problem b has M[b] (device int32) pairs at x1 + b*capM*2 ...;
+ * every problem uses H hypotheses from samples + b*H*8.  Outputs per problem. */
+int mslam_fmat_ransac8_batch_dev(mslam_ctx* ctx, const double* x1, const double* x2, const int32_t* M,
+                                 int capM, const int32_t* samples, int H, int B,
+                                 const mslam_fmat_params* params, double* F, uint8_t* status,
+                                 int32_t* inlier_counts, int32_t* best_h, int32_t* n_inliers);
+
+/* ---- R12: PnP RANSAC ------------------------------------------------------------------
+ * Stands in for `solvePnPRansac(mapPoints, imagePoints, curK, distCoeff, rvec, tvec)`
+ * + Rodrigues (src/CameraPoseEstimator.cpp:472-473).  OpenCV 2.4's implementation is
+ * neither reproducible (threaded, shared RNG) nor available offline; this library keeps
+ * its contract (inputs, inlier rule ||project(X) - x|| < reproj_thr with the distortion
+ * model k1,k2,p1,p2,k3, outputs rvec/tvec) with a deterministic core: hypothesis h is
+ * the P3P pose of sample points 0..2 disambiguated by sample point 3; the best hypothesis
+ * is refined by Gauss-Newton on its inliers. */
+typedef struct {
+    double reproj_thr;   /* 8.0 (OpenCV 2.4 default); BASELINE config C2 uses 2.0 */
+    double confidence;   /* as mslam_fmat_params; <= 0 -> off */
+    int refine_iters;    /* Gauss-Newton iterations on the inlier set (10); 0 = none */
+    int min_inliers;     /* fewer -> MSLAM_ERR_DEGENERATE (OpenCV: 100; default here 4) */
+} mslam_pnp_params;
+void mslam_pnp_default_params(mslam_pnp_params* p);
+
+/* X: P x 3 world points, x: P x 2 pixels, K: row-major 3x3, dist: 8 coefficients
+ * (k1,k2,p1,p2,k3,k4,k5,k6; only the first five are used, as the reference sets,
+ * :462-469), samples: H x 4 indices.  rvec/tvec: world->camera.  inliers: P bytes. */
+int mslam_pnp_ransac(mslam_ctx* ctx, const double* X, const double* x, int P, const double K[9],
+                     const double dist[8], const int32_t* samples, int H,
+                     const mslam_pnp_params* params, double rvec[3], double tvec[3],
+                     double Rt[12], uint8_t* inliers, int32_t* inlier_counts, int* best_h,
+                     int* n_inliers);
+/* Batched, device-resident; problem b: P[b] points at X + b*capP*3, x + b*capP*2,
+ * K + b*9, dist + b*8, samples + b*H*4.  Outputs Rt (B x 12 row-major 3x4), rvec/tvec
+ * (B x 3, optional), inliers (B x capP), inlier_counts (B x H, optional), best_h, n_inliers. */
+int mslam_pnp_ransac_batch_dev(mslam_ctx* ctx, const double* X, const double* x, const int32_t* P,
+                               int capP, const double* K, const double* dist,
+                               const int32_t* samples, int H, int B, const mslam_pnp_params* params,
+                               double* Rt, double* rvec, double* tvec, uint8_t* inliers,
+                               int32_t* inlier_counts, int32_t* best_h, int32_t* n_inliers);
+
+/* ---- R11: two-view DLT triangulation --------------------------------------------------
+ * Stands in for TriangulateMultiplePointsFromTwoView / TriangulateSinglePointFromTwoView
+ * (src/CameraPoseEstimator.cpp:86-152).  Rt1,Rt2: row-major 3x4; K1,K2: 3x3.
+ * X: n x 3.  front (optional): n bytes, 1 iff z > 0 in both cameras.  n_front optional. */
+int mslam_triangulate(mslam_ctx* ctx, const double* x1, const double* x2, int n,
+                      const double Rt1[12], const double Rt2[12], const double K1[9], const double K2[9],
+                      double* X, uint8_t* front, int* n_front);
+
+/* ---- R14-R17: bundle-adjustment linearisation ----------------------------------------
+ * Stands in for one pass of g2o's BlockSolver<6,3>::buildSystem
+ * (ThirdParty/g2o/g2o/core/block_solver.hpp:502-560) over the graph that
+ * Util::BundleAdjustment builds (src/Util.cpp:34-170): per edge
+ * EdgeSE3ProjectXYZ::computeError (types/types_six_dof_expmap.h:90-95), ::linearizeOplus
+ * (types_six_dof_expmap.cpp:103-139), Huber weighting (core/robust_kernel_impl.cpp:78-91)
+ * and BaseBinaryEdge::constructQuadraticForm (core/base_binary_edge.hpp:55-120). */
+typedef struct {
+    int n_poses, n_points, n_edges;
+    const double* poses;        /* n_poses x 7: tx,ty,tz,qx,qy,qz,qw (world->camera, unit q, w >= 0) */
+    const uint8_t* pose_fixed;  /* n_poses: 1 = fixed (frame id 0 in the reference, src/Util.cpp:72) */
+    const double* points;       /* n_points x 3 */
+    const int32_t* edge_pose;   /* n_edges */
+    const int32_t* edge_point;  /* n_edges */
+    const double* obs;          /* n_edges x 2 */
+    const double* info;         /* n_edges: Omega = info * I2 (src/Util.cpp:151-153) */
+    const double* intr;         /* n_poses x 4: fx,fy,cx,cy (src/Util.cpp:161-164) */
+    double huber_delta;         /* <= 0: no robust kernel */
+} mslam_ba_problem;
+
+/* Layout of the linear system (what the host-side Schur/LDLt solve consumes):
+ *  free poses are numbered in pose order skipping fixed ones (g2o index mapping,
+ *  core/sparse_optimizer.cpp:166-190); fp = number of free poses.
+ *  Hpp: fp x 36 (row-major 6x6, rotation (omega) first then translation (upsilon)).
+ *  Hll: n_points x 9 (row-major 3x3).
+ *  Hpl: block-CSR, rows = free poses, columns = points, sorted by column inside a row;
+ *       Hpl_rowptr fp+1, Hpl_col nnzb, Hpl_val nnzb x 18 (row-major 6x3 = B^T w Omega A).
+ *  b: 6*fp + 3*n_points (poses first, then points; b = -J^T w Omega e).
+ *  err: n_edges x 2, chi2: n_edges (e^T Omega e), rho1: n_edges (Huber weight rho'). */
+typedef struct {
+    double* err;
+    double* chi2;
+    double* rho1;
+    double* Hpp;
+    double* Hll;
+    int32_t* Hpl_rowptr;
+    int32_t* Hpl_col;
+    double* Hpl_val;
+    double* b;
+    double robust_chi2;   /* sum of rho(chi2) (core/sparse_optimizer.cpp:100-114) */
+    int n_free_poses;
+    int nnzb;
+} mslam_ba_system;
+
+/* Host-pointer, one-shot: analyses the structure and builds the system. The caller
+ * sizes the outputs with mslam_ba_sizes (nnzb = edges whose pose is free). */
+int mslam_ba_sizes(const mslam_ba_problem* p, int* n_free_poses, int* nnzb);
+int mslam_ba_build(mslam_ctx* ctx, const mslam_ba_problem* p, mslam_ba_system* s);
+
+/* Persistent form for the LM loop: the structure (index mapping, CSR, edge orders) is
+ * analysed once (g2o: BlockSolver::buildStructure, block_solver.hpp:143-295) and kept on
+ * the device; each relinearisation only uploads/reads state. */
+typedef struct mslam_ba_plan mslam_ba_plan;
+int mslam_ba_plan_create(mslam_ctx* ctx, const mslam_ba_problem* p, mslam_ba_plan** plan);
+void mslam_ba_plan_destroy(mslam_ba_plan* plan);
+/* device views of the plan's state and of the system it builds (all device pointers) */
+typedef struct {
+    double* poses; double* points;         /* state: n_poses x 7, n_points x 3 */
+    double* err; double* chi2; double* rho1;
+    double* Hpp; double* Hll; double* Hpl_val; double* b;
+    int32_t* Hpl_rowptr; int32_t* Hpl_col;
+    double* robust_chi2;                   /* 1 double */
+    int n_free_poses, nnzb;
+} mslam_ba_dev_view;
+int mslam_ba_plan_view(mslam_ba_plan* plan, mslam_ba_dev_view* view);
+int mslam_ba_plan_set_state(mslam_ba_plan* plan, const double* poses_host, const double* points_host);
+/* enqueue one linearisation on the context's stream (no sync) */
+int mslam_ba_plan_build_dev(mslam_ba_plan* plan);
+/* copy the built system to host buffers (syncs) */
+int mslam_ba_plan_download(mslam_ba_plan* plan, mslam_ba_system* s);
+
+/* ---- multi-GPU -------------------------------------------------------------------------
+ * The path shards by independent streams (one process per GPU, no data-path collective).
+ * The only exchange is the optional sharding of ONE problem's hypotheses over ranks:
+ * every rank scores its slice and the int32 inlier counts are all-gathered (RCCL, by
+ * the host side through torch.distributed); the global winner is then
+ * mslam_argmax_counts over the gathered vector (max count, lowest index on ties). */
+int mslam_argmax_counts(const int32_t* counts, int n, int* best, int* best_count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MSLAM_H */

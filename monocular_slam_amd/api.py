@@ -1,0 +1,267 @@
+"""ctypes binding of libmslam_hip.so (C ABI: include/mslam.h).
+
+This is the only way Python reaches the compute path, and there is no fallback: if the
+library is not built, or no gfx950 device is present, the calls raise.  The class names
+mirror the reference's stage vocabulary (src/FeatureExtractor.cpp, src/CameraPoseEstimator.cpp,
+src/Optimiser.cpp); the C++ stage classes under monocular_slam_amd/host bind the same
+entry points.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmslam_hip.so")
+
+u8p = C.POINTER(C.c_uint8)
+i32p = C.POINTER(C.c_int32)
+f32p = C.POINTER(C.c_float)
+f64p = C.POINTER(C.c_double)
+vp = C.c_void_p
+
+OK, ERR_INVALID, ERR_HIP, ERR_CAPACITY, ERR_TOO_FEW, ERR_NO_DEVICE, ERR_DEGENERATE = 0, -1, -2, -3, -4, -5, -6
+
+
+class MslamError(RuntimeError):
+    def __init__(self, status: int, what: str, detail: str = ""):
+        self.status = status
+        super().__init__(f"{what}: status {status}" + (f" ({detail})" if detail else ""))
+
+
+class OrbParams(C.Structure):
+    _fields_ = [("nfeatures", C.c_int), ("scale_factor", C.c_float), ("nlevels", C.c_int),
+                ("edge_threshold", C.c_int), ("first_level", C.c_int), ("wta_k", C.c_int),
+                ("score_type", C.c_int), ("patch_size", C.c_int), ("fast_threshold", C.c_int)]
+
+
+class FmatParams(C.Structure):
+    _fields_ = [("metric", C.c_int), ("threshold", C.c_double), ("confidence", C.c_double), ("refit", C.c_int)]
+
+
+class PnpParams(C.Structure):
+    _fields_ = [("reproj_thr", C.c_double), ("confidence", C.c_double), ("refine_iters", C.c_int),
+                ("min_inliers", C.c_int)]
+
+
+class BaProblem(C.Structure):
+    _fields_ = [("n_poses", C.c_int), ("n_points", C.c_int), ("n_edges", C.c_int),
+                ("poses", f64p), ("pose_fixed", u8p), ("points", f64p),
+                ("edge_pose", i32p), ("edge_point", i32p), ("obs", f64p), ("info", f64p),
+                ("intr", f64p), ("huber_delta", C.c_double)]
+
+
+class BaSystem(C.Structure):
+    _fields_ = [("err", f64p), ("chi2", f64p), ("rho1", f64p), ("Hpp", f64p), ("Hll", f64p),
+                ("Hpl_rowptr", i32p), ("Hpl_col", i32p), ("Hpl_val", f64p), ("b", f64p),
+                ("robust_chi2", C.c_double), ("n_free_poses", C.c_int), ("nnzb", C.c_int)]
+
+
+class BaDevView(C.Structure):
+    _fields_ = [("poses", vp), ("points", vp), ("err", vp), ("chi2", vp), ("rho1", vp),
+                ("Hpp", vp), ("Hll", vp), ("Hpl_val", vp), ("b", vp), ("Hpl_rowptr", vp), ("Hpl_col", vp),
+                ("robust_chi2", vp), ("n_free_poses", C.c_int), ("nnzb", C.c_int)]
+
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
+                     ("octave", "<i4")])
+
+_LIB = None
+
+
+def lib() -> C.CDLL:
+    """Load libmslam_hip.so; raises if it has not been built (no CPU fallback exists)."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise MslamError(ERR_NO_DEVICE, "libmslam_hip.so is not built",
+                             "run `python -c 'import __graft_entry__ as g; g.build()'` or make -C monocular_slam_amd/csrc")
+        L = C.CDLL(LIB_PATH)
+        L.mslam_strerror.restype = C.c_char_p
+        L.mslam_last_hip_error.restype = C.c_char_p
+        L.mslam_last_hip_error.argtypes = [vp]
+        L.mslam_stream.restype = vp
+        L.mslam_stream.argtypes = [vp]
+        _LIB = L
+    return _LIB
+
+
+def _p(a, t):
+    return a.ctypes.data_as(t)
+
+
+def default_orb_params(nfeatures: int = 500) -> OrbParams:
+    p = OrbParams()
+    lib().mslam_orb_default_params(C.byref(p))
+    p.nfeatures = nfeatures
+    return p
+
+
+class Context:
+    """One context per GPU (mslam_create)."""
+
+    def __init__(self, device: int = 0, max_w: int = 1920, max_h: int = 1080, max_kpts: int = 4096, batch: int = 1):
+        self._h = vp()
+        self.max_kpts = max_kpts
+        self.batch = batch
+        rc = lib().mslam_create(C.byref(self._h), device, max_w, max_h, max_kpts, batch)
+        if rc != OK:
+            self._h = None
+            raise MslamError(rc, "mslam_create", lib().mslam_strerror(rc).decode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().mslam_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _check(self, rc: int, what: str):
+        if rc != OK:
+            detail = lib().mslam_strerror(rc).decode()
+            if rc == ERR_HIP:
+                detail += ": " + lib().mslam_last_hip_error(self._h).decode()
+            raise MslamError(rc, what, detail)
+
+    @property
+    def handle(self):
+        return self._h
+
+    def sync(self):
+        self._check(lib().mslam_sync(self._h), "mslam_sync")
+
+    # ---- timing on the context's stream
+    def event(self):
+        e = vp()
+        self._check(lib().mslam_event_create(self._h, C.byref(e)), "mslam_event_create")
+        return e
+
+    def record(self, e):
+        self._check(lib().mslam_event_record(self._h, e), "mslam_event_record")
+
+    def elapsed_ms(self, a, b) -> float:
+        ms = C.c_float(0)
+        self._check(lib().mslam_event_elapsed_ms(self._h, a, b, C.byref(ms)), "mslam_event_elapsed_ms")
+        return float(ms.value)
+
+    # ---- R1-R6
+    def orb_extract(self, img: np.ndarray, params: OrbParams, cap: int | None = None):
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        h, w = img.shape[:2]
+        ch = 1 if img.ndim == 2 else img.shape[2]
+        if cap is None:
+            cap = self.max_kpts
+        kps = np.zeros(cap, dtype=KP_DTYPE)
+        desc = np.zeros((cap, 32), dtype=np.uint8)
+        n = C.c_int(0)
+        rc = lib().mslam_orb_extract(self._h, _p(img, u8p), w, h, w * ch, ch, C.byref(params),
+                                     kps.ctypes.data_as(vp), _p(desc, u8p), cap, C.byref(n))
+        self._check(rc, "mslam_orb_extract")
+        return kps[: n.value].copy(), desc[: n.value].copy()
+
+    def orb_debug_level(self, level: int, blurred: bool, max_w: int, max_h: int):
+        out = np.zeros(max_w * max_h, dtype=np.uint8)
+        lw, lh = C.c_int(0), C.c_int(0)
+        self._check(lib().mslam_orb_debug_level(self._h, level, int(blurred), _p(out, u8p), C.byref(lw), C.byref(lh)),
+                    "mslam_orb_debug_level")
+        return out[: lw.value * lh.value].reshape(lh.value, lw.value).copy()
+
+    def orb_extract_batch_dev(self, imgs_ptr: int, B: int, w: int, h: int, stride: int, frame_stride: int, channels: int,
+                              params: OrbParams, kps_ptr: int, desc_ptr: int, cap: int, n_out_ptr: int, status_ptr: int = 0):
+        rc = lib().mslam_orb_extract_batch_dev(self._h, vp(imgs_ptr), B, w, h, stride, C.c_int64(frame_stride), channels,
+                                               C.byref(params), vp(kps_ptr), vp(desc_ptr), cap, vp(n_out_ptr),
+                                               vp(status_ptr) if status_ptr else None)
+        self._check(rc, "mslam_orb_extract_batch_dev")
+
+    # ---- R7
+    def match_knn2(self, q: np.ndarray, t: np.ndarray):
+        q = np.ascontiguousarray(q, dtype=np.uint8)
+        t = np.ascontiguousarray(t, dtype=np.uint8)
+        nq, nt = q.shape[0], t.shape[0]
+        idx = np.zeros((nq, 2), np.int32)
+        dist = np.zeros((nq, 2), np.int32)
+        rc = lib().mslam_match_knn2(self._h, _p(q, u8p), nq, _p(t, u8p), nt, _p(idx, i32p), _p(dist, i32p))
+        self._check(rc, "mslam_match_knn2")
+        return idx, dist
+
+    def match_knn2_batch_dev(self, q_ptr, nq_ptr, t_ptr, nt_ptr, cap, B, idx_ptr, dist_ptr, ratio=0.0,
+                             m_query_ptr=0, m_train_ptr=0, m_dist_ptr=0, m_count_ptr=0):
+        def o(p):
+            return vp(p) if p else None
+        rc = lib().mslam_match_knn2_batch_dev(self._h, vp(q_ptr), vp(nq_ptr), vp(t_ptr), vp(nt_ptr), cap, B,
+                                              vp(idx_ptr), vp(dist_ptr), C.c_float(ratio), o(m_query_ptr), o(m_train_ptr),
+                                              o(m_dist_ptr), o(m_count_ptr))
+        self._check(rc, "mslam_match_knn2_batch_dev")
+
+
+class DevBuf:
+    """A device buffer owned through the C ABI (mslam_dev_alloc / mslam_memcpy_*).
+
+    The library is linked against the system HIP runtime; PyTorch wheels bundle their own
+    copy, so device pointers are never shared between the two -- torch is used for
+    torch.distributed only.
+    """
+
+    def __init__(self, ctx: Context, nbytes: int):
+        self.ctx = ctx
+        self.nbytes = int(nbytes)
+        self._p = vp()
+        ctx._check(lib().mslam_dev_alloc(ctx.handle, C.byref(self._p), C.c_uint64(max(1, self.nbytes))), "mslam_dev_alloc")
+
+    @classmethod
+    def from_array(cls, ctx: Context, a: np.ndarray) -> "DevBuf":
+        a = np.ascontiguousarray(a)
+        b = cls(ctx, a.nbytes)
+        b.upload(a)
+        return b
+
+    @property
+    def ptr(self) -> int:
+        return int(self._p.value or 0)
+
+    def upload(self, a: np.ndarray, offset: int = 0):
+        a = np.ascontiguousarray(a)
+        assert offset + a.nbytes <= self.nbytes
+        self.ctx._check(lib().mslam_memcpy_h2d(self.ctx.handle, vp(self.ptr + offset), a.ctypes.data_as(vp), C.c_uint64(a.nbytes)),
+                        "mslam_memcpy_h2d")
+
+    def download(self, dtype, shape, offset: int = 0) -> np.ndarray:
+        out = np.empty(shape, dtype=dtype)
+        assert offset + out.nbytes <= self.nbytes
+        self.ctx._check(lib().mslam_memcpy_d2h(self.ctx.handle, out.ctypes.data_as(vp), vp(self.ptr + offset), C.c_uint64(out.nbytes)),
+                        "mslam_memcpy_d2h")
+        return out
+
+    def free(self):
+        if self._p and self._p.value and self.ctx.handle:
+            lib().mslam_dev_free(self.ctx.handle, self._p)
+            self._p = vp()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def ratio_filter(idx: np.ndarray, dist: np.ndarray, ratio: float):
+    nq = idx.shape[0]
+    qi = np.zeros(nq, np.int32); ti = np.zeros(nq, np.int32); d = np.zeros(nq, np.float32)
+    n = C.c_int(0)
+    rc = lib().mslam_ratio_filter(_p(np.ascontiguousarray(idx, np.int32), i32p), _p(np.ascontiguousarray(dist, np.int32), i32p),
+                                  nq, C.c_float(ratio), _p(qi, i32p), _p(ti, i32p), _p(d, f32p), C.byref(n))
+    if rc != OK:
+        raise MslamError(rc, "mslam_ratio_filter")
+    return qi[: n.value].copy(), ti[: n.value].copy(), d[: n.value].copy()

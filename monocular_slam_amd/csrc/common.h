@@ -1,0 +1,62 @@
+// common.h -- internal definitions of libmslam_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include "../../include/mslam.h"
+
+#define MSLAM_ABI_VERSION 1000
+
+struct OrbPlan;   // orb.hip
+struct MatchScratch;
+
+struct mslam_ctx {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    int max_w = 0, max_h = 0, max_kpts = 0, batch = 1;
+    std::string last_hip_error;
+    OrbPlan* orb = nullptr;            // geometry-dependent ORB scratch (lazily built)
+    // generic scratch arena, grown on demand (never inside a timed loop once warm)
+    void* scratch = nullptr;
+    size_t scratch_bytes = 0;
+    // second arena for the host-pointer convenience wrappers (staging of inputs/outputs)
+    void* stage = nullptr;
+    size_t stage_bytes = 0;
+};
+
+// record + return on HIP failure
+#define HIP_TRY(ctx, expr)                                                         \
+    do {                                                                           \
+        hipError_t _e = (expr);                                                    \
+        if (_e != hipSuccess) {                                                    \
+            (ctx)->last_hip_error = std::string(#expr) + ": " + hipGetErrorString(_e); \
+            return MSLAM_ERR_HIP;                                                  \
+        }                                                                          \
+    } while (0)
+
+#define MSLAM_TRY(expr)            \
+    do {                           \
+        int _s = (expr);           \
+        if (_s != MSLAM_OK) return _s; \
+    } while (0)
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// grows (never shrinks) the scratch arena; contents are not preserved
+int ctx_scratch(mslam_ctx* ctx, size_t bytes, void** out);
+int ctx_stage(mslam_ctx* ctx, size_t bytes, void** out);
+int ctx_set_device(mslam_ctx* ctx);
+
+// bump allocator over an arena
+struct Bump {
+    char* base; size_t off; size_t cap;
+    template <typename T> T* take(size_t n) {
+        off = align_up(off, 256);
+        T* p = reinterpret_cast<T*>(base + off);
+        off += n * sizeof(T);
+        return p;
+    }
+};
+
+void orb_plan_destroy(mslam_ctx* ctx);

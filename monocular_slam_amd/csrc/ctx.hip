@@ -1,0 +1,177 @@
+// ctx.hip -- context, memory and timing helpers of the C ABI (include/mslam.h).
+#include "common.h"
+#include <cstring>
+
+extern "C" {
+
+int mslam_abi_version(void) { return MSLAM_ABI_VERSION; }
+
+const char* mslam_strerror(int s)
+{
+    switch (s) {
+        case MSLAM_OK: return "ok";
+        case MSLAM_ERR_INVALID: return "invalid argument";
+        case MSLAM_ERR_HIP: return "HIP runtime error";
+        case MSLAM_ERR_CAPACITY: return "result exceeds the given capacity";
+        case MSLAM_ERR_TOO_FEW: return "too few rows/points";
+        case MSLAM_ERR_NO_DEVICE: return "no usable gfx950 device";
+        case MSLAM_ERR_DEGENERATE: return "no valid model";
+        default: return "unknown status";
+    }
+}
+
+int mslam_create(mslam_ctx** out, int device, int max_w, int max_h, int max_kpts, int batch)
+{
+    if (!out || max_w < 16 || max_h < 16 || max_w > 4095 || max_h > 4095 || max_kpts < 8 || max_kpts > 65535 || batch < 1)
+        return MSLAM_ERR_INVALID;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev)
+        return MSLAM_ERR_NO_DEVICE;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return MSLAM_ERR_NO_DEVICE;
+    // this library carries gfx950 code objects only
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return MSLAM_ERR_NO_DEVICE;
+    mslam_ctx* ctx = new mslam_ctx();
+    ctx->device = device;
+    ctx->max_w = max_w; ctx->max_h = max_h; ctx->max_kpts = max_kpts; ctx->batch = batch;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete ctx;
+        return MSLAM_ERR_HIP;
+    }
+    *out = ctx;
+    return MSLAM_OK;
+}
+
+void mslam_destroy(mslam_ctx* ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    orb_plan_destroy(ctx);
+    if (ctx->scratch) (void)hipFree(ctx->scratch);
+    if (ctx->stage) (void)hipFree(ctx->stage);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int mslam_sync(mslam_ctx* ctx)
+{
+    if (!ctx) return MSLAM_ERR_INVALID;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return MSLAM_OK;
+}
+
+void* mslam_stream(mslam_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+const char* mslam_last_hip_error(mslam_ctx* ctx) { return ctx ? ctx->last_hip_error.c_str() : ""; }
+
+int mslam_dev_alloc(mslam_ctx* ctx, void** dptr, uint64_t bytes)
+{
+    if (!ctx || !dptr) return MSLAM_ERR_INVALID;
+    MSLAM_TRY(ctx_set_device(ctx));
+    HIP_TRY(ctx, hipMalloc(dptr, bytes ? bytes : 1));
+    return MSLAM_OK;
+}
+
+int mslam_dev_free(mslam_ctx* ctx, void* dptr)
+{
+    if (!ctx) return MSLAM_ERR_INVALID;
+    MSLAM_TRY(ctx_set_device(ctx));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipFree(dptr));
+    return MSLAM_OK;
+}
+
+int mslam_memcpy_h2d(mslam_ctx* ctx, void* dst, const void* src, uint64_t bytes)
+{
+    if (!ctx || (bytes && (!dst || !src))) return MSLAM_ERR_INVALID;
+    HIP_TRY(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return MSLAM_OK;
+}
+
+int mslam_memcpy_d2h(mslam_ctx* ctx, void* dst, const void* src, uint64_t bytes)
+{
+    if (!ctx || (bytes && (!dst || !src))) return MSLAM_ERR_INVALID;
+    HIP_TRY(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return MSLAM_OK;
+}
+
+int mslam_event_create(mslam_ctx* ctx, void** ev)
+{
+    if (!ctx || !ev) return MSLAM_ERR_INVALID;
+    MSLAM_TRY(ctx_set_device(ctx));
+    hipEvent_t e;
+    HIP_TRY(ctx, hipEventCreate(&e));
+    *ev = (void*)e;
+    return MSLAM_OK;
+}
+
+int mslam_event_destroy(mslam_ctx* ctx, void* ev)
+{
+    if (!ctx || !ev) return MSLAM_ERR_INVALID;
+    HIP_TRY(ctx, hipEventDestroy((hipEvent_t)ev));
+    return MSLAM_OK;
+}
+
+int mslam_event_record(mslam_ctx* ctx, void* ev)
+{
+    if (!ctx || !ev) return MSLAM_ERR_INVALID;
+    HIP_TRY(ctx, hipEventRecord((hipEvent_t)ev, ctx->stream));
+    return MSLAM_OK;
+}
+
+int mslam_event_elapsed_ms(mslam_ctx* ctx, void* a, void* b, float* ms)
+{
+    if (!ctx || !a || !b || !ms) return MSLAM_ERR_INVALID;
+    HIP_TRY(ctx, hipEventSynchronize((hipEvent_t)b));
+    HIP_TRY(ctx, hipEventElapsedTime(ms, (hipEvent_t)a, (hipEvent_t)b));
+    return MSLAM_OK;
+}
+
+int mslam_argmax_counts(const int32_t* counts, int n, int* best, int* best_count)
+{
+    if (!counts || n <= 0 || !best) return MSLAM_ERR_INVALID;
+    int b = 0;
+    for (int i = 1; i < n; i++)
+        if (counts[i] > counts[b]) b = i; // strict: lowest index wins ties
+    *best = b;
+    if (best_count) *best_count = counts[b];
+    return MSLAM_OK;
+}
+
+} // extern "C"
+
+int ctx_set_device(mslam_ctx* ctx)
+{
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return MSLAM_OK;
+}
+
+static int grow(mslam_ctx* ctx, void** buf, size_t* have, size_t bytes)
+{
+    if (bytes <= *have) return MSLAM_OK;
+    MSLAM_TRY(ctx_set_device(ctx));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (*buf) HIP_TRY(ctx, hipFree(*buf));
+    *buf = nullptr; *have = 0;
+    size_t want = align_up(bytes + bytes / 4, 1 << 20);
+    HIP_TRY(ctx, hipMalloc(buf, want));
+    *have = want;
+    return MSLAM_OK;
+}
+
+int ctx_scratch(mslam_ctx* ctx, size_t bytes, void** out)
+{
+    MSLAM_TRY(grow(ctx, &ctx->scratch, &ctx->scratch_bytes, bytes));
+    *out = ctx->scratch;
+    return MSLAM_OK;
+}
+
+int ctx_stage(mslam_ctx* ctx, size_t bytes, void** out)
+{
+    MSLAM_TRY(grow(ctx, &ctx->stage, &ctx->stage_bytes, bytes));
+    *out = ctx->stage;
+    return MSLAM_OK;
+}

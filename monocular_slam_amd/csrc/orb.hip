@@ -1,0 +1,808 @@
+// orb.hip -- K1-K6: ORB keypoint detection + 256-bit rBRIEF description (gfx950).
+//
+// Stands in for cv::ORB as called by FeatureExtractor::process (reference
+// src/FeatureExtractor.cpp:17,19): detect() then compute() on the same frame.  The
+// reference builds the pyramid twice (once per call); here it is built once and both
+// passes read it.
+//
+// HBM layout (per context, batch B frames, level l of size lw x lh):
+//   level[l]   u8  [B][lh][pitch_l]   pitch_l = align64(lw); level 0 aliases the caller's
+//                                      gray frame when it is 1-channel and 4-byte aligned
+//   cand[l]    u32 [B][cap_l]         FAST corners after NMS: score<<24 | y<<12 | x
+//   candA[l]   u32 [B][cap_l]         survivors of retainBest(2n) + respA f32 (Harris)
+//   hist       u32 [B][L][256]        FAST score histogram,  cnt u32 [B][L]
+//   sel        u32x2 [B][L][max_kpts] final per-level keypoints (key, response), row-major
+//   cap_l = ceil(roi_w/2)*ceil(roi_h/2): NMS survivors are never 8-adjacent, so the
+//   candidate list cannot overflow.
+// Kernels (one launch each per batch unless noted):
+//   bgr2gray_k      BGR[A] -> gray, fixed point (only for 3/4-channel input)
+//   resize_k        level l-1 -> l, 11-bit fixed-point bilinear (L-1 launches: serial dependency)
+//   fast_nms_k      all levels x frames: 64x32 pixel tiles staged in LDS with a 4-px halo;
+//                   3-phase (high-speed reject -> dense survivor list -> exact score) so that
+//                   lanes stay busy; 3x3 NMS on an LDS score tile; wave-aggregated append
+//   select_k        one workgroup per (frame, level): histogram threshold (retainBest by
+//                   FAST score), Harris response, radix-select of the n-th best response,
+//                   rank-sort of the survivors by (y, x)
+//   describe_k      one wavefront per keypoint: 43x43 patch in LDS, intensity-centroid
+//                   angle (lane-per-row + wave reduce), separable 7x7 Gaussian of the patch
+//                   (the blurred pyramid is never materialised), 256 rotated tests, 4 ballots
+//                   = 32 descriptor bytes
+// All integer/float arithmetic is the plain-IEEE evaluation documented in DESIGN.md (built
+// with -ffp-contract=off); cvRound = round-half-even (__float2int_rn / rint).
+#include "common.h"
+#include <cmath>
+#include <cstring>
+
+namespace {
+
+__constant__ int8_t c_pattern[256 * 4] = {
+#include "orb_pattern_31.inc"
+};
+// u_max of IC_Angle for half patch 15 (OpenCV computeKeyPoints)
+__constant__ int c_umax[16] = { 15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3 };
+// 7x7 sigma=2 Gaussian, 8-bit fixed point (getGaussianKernel(7,2,CV_32F) * 256, cvRound)
+__constant__ int c_gk[7] = { 18, 34, 49, 55, 49, 34, 18 };
+
+constexpr int FT_W = 64, FT_H = 32;           // FAST output tile
+constexpr int FP_W = FT_W + 8, FP_H = FT_H + 8; // pixel tile (halo 4)
+constexpr int FP_PITCH = 80;                  // LDS row pitch in bytes (20 dwords)
+constexpr int FS_W = FT_W + 2, FS_H = FT_H + 2; // score tile (halo 1)
+constexpr int FAST_THREADS = 256;
+
+struct LevelDesc {
+    uint8_t* img; int w, h, pitch; long long frame_stride; // bytes
+    int roi_x0, roi_y0, roi_w, roi_h;  // [edge, w-edge) x [edge, h-edge)
+    int tiles_x, tiles_y, tile_base;   // tile_base: first tile index of this level in the all-level grid
+    int cand_cap; uint32_t* cand; uint32_t* candA; float* respA;
+    int nfeat; float sf, inv_sf;
+    int4* xtab; int4* ytab;            // resize tables for producing THIS level from l-1
+};
+
+struct OrbDev {
+    LevelDesc lv[MSLAM_MAX_LEVELS];
+    int L, B, max_kpts, edge, fast_thr, score_type, tiles_per_frame;
+    uint32_t* hist;   // [B][L][256]
+    uint32_t* cnt;    // [B][L] candidate counts
+    uint2* sel;       // [B][L][max_kpts]
+    int32_t* sel_cnt; // [B][L]
+    int32_t* frame_status; // [B]
+};
+
+// ---------------------------------------------------------------- K1: gray + pyramid
+__global__ void bgr2gray_k(const uint8_t* __restrict__ src, int w, int h, int stride, long long fstride, int ch,
+                           uint8_t* __restrict__ dst, int dpitch, long long dfstride)
+{
+    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, b = blockIdx.z;
+    if (x >= w) return;
+    const uint8_t* s = src + b * fstride + (size_t)y * stride + (size_t)x * ch;
+    int v = ch == 1 ? s[0] : (s[0] * 1868 + s[1] * 9617 + s[2] * 4899 + (1 << 13)) >> 14;
+    dst[b * dfstride + (size_t)y * dpitch + x] = (uint8_t)v;
+}
+
+// 4 destination pixels per thread, packed 32-bit store
+__global__ __launch_bounds__(256)
+void resize_k(const uint8_t* __restrict__ src, int spitch, long long sfstride,
+              uint8_t* __restrict__ dst, int dw, int dh, int dpitch, long long dfstride,
+              const int4* __restrict__ xtab, const int4* __restrict__ ytab)
+{
+    const int x4 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    const int y = blockIdx.y, b = blockIdx.z;
+    if (x4 >= dw) return;
+    const int4 yt = ytab[y]; // {sy0, sy1, b0, b1}
+    const uint8_t* r0 = src + b * sfstride + (size_t)yt.x * spitch;
+    const uint8_t* r1 = src + b * sfstride + (size_t)yt.y * spitch;
+    uint32_t out = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        int x = x4 + i;
+        if (x < dw) {
+            const int4 xt = xtab[x]; // {sx0, sx1, a0, a1}
+            int S0 = r0[xt.x] * xt.z + r0[xt.y] * xt.w;
+            int S1 = r1[xt.x] * xt.z + r1[xt.y] * xt.w;
+            int v = (((yt.z * (S0 >> 4)) >> 16) + ((yt.w * (S1 >> 4)) >> 16) + 2) >> 2;
+            out |= (uint32_t)(v & 255) << (8 * i);
+        }
+    }
+    *reinterpret_cast<uint32_t*>(dst + b * dfstride + (size_t)y * dpitch + x4) = out;
+}
+
+// ---------------------------------------------------------------- K2: FAST-9/16 + NMS
+__device__ __forceinline__ int ring_ofs(int k)
+{
+    // Bresenham circle r=3 in FAST's order, as byte offsets in the LDS pixel tile
+    constexpr int dx[16] = { 0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1 };
+    constexpr int dy[16] = { 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3 };
+    return dy[k] * FP_PITCH + dx[k];
+}
+
+// exact cornerScore<16>: max over the 16 arcs of 9 of min(d) / min(-d), minus 1
+__device__ __forceinline__ int fast_exact_score(const int* d)
+{
+    int m2[16], m4[16], m8[16];
+    int n2[16], n4[16], n8[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) { m2[k] = min(d[k], d[(k + 1) & 15]); n2[k] = max(d[k], d[(k + 1) & 15]); }
+#pragma unroll
+    for (int k = 0; k < 16; k++) { m4[k] = min(m2[k], m2[(k + 2) & 15]); n4[k] = max(n2[k], n2[(k + 2) & 15]); }
+#pragma unroll
+    for (int k = 0; k < 16; k++) { m8[k] = min(m4[k], m4[(k + 4) & 15]); n8[k] = max(n4[k], n4[(k + 4) & 15]); }
+    int amax = -256, bmin = 256;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        amax = max(amax, min(m8[k], d[(k + 8) & 15]));
+        bmin = min(bmin, max(n8[k], d[(k + 8) & 15]));
+    }
+    return max(amax, -bmin) - 1;
+}
+
+__global__ __launch_bounds__(FAST_THREADS)
+void fast_nms_k(OrbDev od)
+{
+    __shared__ uint32_t s_pix[FP_H * FP_PITCH / 4];
+    __shared__ uint8_t s_score[FS_H * FS_W + 4];
+    __shared__ uint16_t s_list[FS_H * FS_W];
+    __shared__ uint32_t s_emit[FT_W * FT_H / 4 + 64];
+    __shared__ int s_n1, s_n2, s_ne, s_base;
+
+    // tile -> (frame, level, tx, ty): blocks of one frame are consecutive
+    const int b = blockIdx.x / od.tiles_per_frame;
+    int t = blockIdx.x % od.tiles_per_frame;
+    int l = 0;
+    while (l + 1 < od.L && t >= od.lv[l + 1].tile_base) l++;
+    const LevelDesc& lv = od.lv[l];
+    t -= lv.tile_base;
+    const int tx = t % lv.tiles_x, ty = t / lv.tiles_x;
+    const int ox = lv.roi_x0 + tx * FT_W, oy = lv.roi_y0 + ty * FT_H; // first output pixel
+    const int px0 = ox - 4, py0 = oy - 4;                             // pixel tile origin
+    const uint8_t* img = lv.img + b * lv.frame_stride;
+    const int tid = threadIdx.x;
+
+    if (tid == 0) { s_n1 = 0; s_n2 = 0; s_ne = 0; }
+    for (int i = tid; i < (FS_H * FS_W + 4) / 4; i += FAST_THREADS) reinterpret_cast<uint32_t*>(s_score)[i] = 0;
+    // stage the pixel tile with aligned dword loads; xo = misalignment of the tile origin
+    const int xa = px0 & ~3, xo = px0 & 3;
+    const int max_dw = lv.pitch / 4 - 1;
+    for (int i = tid; i < FP_H * (FP_PITCH / 4); i += FAST_THREADS) {
+        int r = i / (FP_PITCH / 4), c = i % (FP_PITCH / 4);
+        int gy = min(py0 + r, lv.h - 1);
+        int gdw = min(xa / 4 + c, max_dw);
+        s_pix[i] = reinterpret_cast<const uint32_t*>(img + (size_t)gy * lv.pitch)[gdw];
+    }
+    __syncthreads();
+    const uint8_t* pix = reinterpret_cast<const uint8_t*>(s_pix) + xo; // pix[r*FP_PITCH + c], (r,c) relative to (py0,px0)
+    const int thr = od.fast_thr;
+    // score region: (sx,sy) in [0,FS_W)x[0,FS_H) <-> pixel (ox-1+sx, oy-1+sy) <-> tile coords (sx+3, sy+3)
+    const int lim_x = min(FS_W, lv.roi_x0 + lv.roi_w + 1 - (ox - 1)); // scores only needed up to ROI+1
+    const int lim_y = min(FS_H, lv.roi_y0 + lv.roi_h + 1 - (oy - 1));
+    // ---- phase 1: high-speed rejection (an arc of 9 contains ring pixel 0 or 8, and 4 or 12)
+    for (int i0 = 0; i0 < FS_H * FS_W; i0 += FAST_THREADS) {
+        int i = i0 + tid;
+        bool pass = false;
+        if (i < FS_H * FS_W) {
+            int sy = i / FS_W, sx = i % FS_W;
+            if (sx < lim_x && sy < lim_y) {
+                const uint8_t* p = pix + (sy + 3) * FP_PITCH + (sx + 3);
+                int v = p[0];
+                int d0 = v - p[ring_ofs(0)], d8 = v - p[ring_ofs(8)];
+                bool a = (abs(d0) > thr) | (abs(d8) > thr);
+                int d4 = v - p[ring_ofs(4)], d12 = v - p[ring_ofs(12)];
+                bool c = (abs(d4) > thr) | (abs(d12) > thr);
+                pass = a & c;
+            }
+        }
+        unsigned long long bal = __ballot(pass);
+        int base = 0;
+        if ((tid & 63) == 0 && bal) base = atomicAdd(&s_n1, __popcll(bal));
+        base = __shfl(base, 0);
+        if (pass) s_list[base + __popcll(bal & ((1ull << (tid & 63)) - 1ull))] = (uint16_t)i;
+    }
+    __syncthreads();
+    // ---- phase 2: segment test + exact score for the survivors (dense lanes)
+    const int n1 = s_n1;
+    for (int j = tid; j < n1; j += FAST_THREADS) {
+        int i = s_list[j];
+        int sy = i / FS_W, sx = i % FS_W;
+        const uint8_t* p = pix + (sy + 3) * FP_PITCH + (sx + 3);
+        int v = p[0];
+        int d[16];
+        uint32_t mb = 0, md = 0; // ring brighter than v+thr / darker than v-thr
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            d[k] = v - p[ring_ofs(k)];
+            mb |= (uint32_t)(d[k] < -thr) << k;
+            md |= (uint32_t)(d[k] > thr) << k;
+        }
+        mb |= mb << 16; md |= md << 16;
+        uint32_t rb = mb & (mb >> 1); rb &= rb >> 2; rb &= rb >> 4; rb &= mb >> 8; // 9 contiguous
+        uint32_t rd = md & (md >> 1); rd &= rd >> 2; rd &= rd >> 4; rd &= md >> 8;
+        if (((rb | rd) & 0xFFFFu) != 0) s_score[sy * FS_W + sx] = (uint8_t)fast_exact_score(d);
+    }
+    __syncthreads();
+    // ---- phase 3: 3x3 non-max suppression on the score tile, outputs inside the ROI only
+    const int out_w = min(FT_W, lv.roi_x0 + lv.roi_w - ox), out_h = min(FT_H, lv.roi_y0 + lv.roi_h - oy);
+    for (int j = tid; j < n1; j += FAST_THREADS) {
+        int i = s_list[j];
+        int sy = i / FS_W, sx = i % FS_W;
+        int s = s_score[i];
+        if (s == 0 || sx < 1 || sy < 1 || sx > out_w || sy > out_h) continue;
+        const uint8_t* c = s_score + i;
+        bool mx = s > c[-1] && s > c[1] && s > c[-FS_W - 1] && s > c[-FS_W] && s > c[-FS_W + 1] &&
+                  s > c[FS_W - 1] && s > c[FS_W] && s > c[FS_W + 1];
+        if (mx) {
+            int e = atomicAdd(&s_ne, 1);
+            int gx = ox - 1 + sx, gy = oy - 1 + sy;
+            s_emit[e] = ((uint32_t)s << 24) | ((uint32_t)gy << 12) | (uint32_t)gx;
+            atomicAdd(&od.hist[((size_t)b * od.L + l) * 256 + s], 1u);
+        }
+    }
+    __syncthreads();
+    const int ne = s_ne;
+    if (ne == 0) return;
+    if (tid == 0) s_base = (int)atomicAdd(&od.cnt[b * od.L + l], (uint32_t)ne);
+    __syncthreads();
+    uint32_t* cand = lv.cand + (size_t)b * lv.cand_cap;
+    for (int j = tid; j < ne; j += FAST_THREADS)
+        if (s_base + j < lv.cand_cap) cand[s_base + j] = s_emit[j];
+}
+
+// ---------------------------------------------------------------- K3: select
+constexpr int SEL_THREADS = 1024;
+constexpr int SEL_LEVEL_CAP = 4096; // survivors of one level are rank-sorted in LDS (32 KiB)
+
+__device__ __forceinline__ float harris_response(const uint8_t* __restrict__ img, int pitch, int x, int y)
+{
+    // HarrisResponses(img, pts, 7, 0.04f): 7x7 block of Sobel-like gradients from a 9x9 window
+    int a = 0, bb = 0, c = 0;
+    int win[9][9];
+    const uint8_t* p = img + (size_t)(y - 4) * pitch + (x - 4);
+#pragma unroll
+    for (int r = 0; r < 9; r++)
+#pragma unroll
+        for (int j = 0; j < 9; j++) win[r][j] = p[(size_t)r * pitch + j];
+#pragma unroll
+    for (int r = 1; r <= 7; r++)
+#pragma unroll
+        for (int j = 1; j <= 7; j++) {
+            int Ix = (win[r][j + 1] - win[r][j - 1]) * 2 + (win[r - 1][j + 1] - win[r - 1][j - 1]) + (win[r + 1][j + 1] - win[r + 1][j - 1]);
+            int Iy = (win[r + 1][j] - win[r - 1][j]) * 2 + (win[r + 1][j - 1] - win[r - 1][j - 1]) + (win[r + 1][j + 1] - win[r - 1][j + 1]);
+            a += Ix * Ix; bb += Iy * Iy; c += Ix * Iy;
+        }
+    float scale = (1 << 2) * 7 * 255.0f;
+    scale = 1.0f / scale;
+    float scale_sq_sq = scale * scale * scale * scale;
+    return ((float)a * bb - (float)c * c - 0.04f * ((float)a + bb) * ((float)a + bb)) * scale_sq_sq;
+}
+
+__device__ __forceinline__ uint32_t float_key(float f)
+{
+    uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u); // order-preserving
+}
+
+__global__ __launch_bounds__(SEL_THREADS)
+void select_k(OrbDev od)
+{
+    extern __shared__ uint8_t dyn[];  // survivors: uint2[max_kpts]
+    __shared__ uint32_t s_hist[256];
+    __shared__ int s_T, s_nA, s_nS;
+    __shared__ uint32_t s_prefix, s_mask;
+    __shared__ int s_k;
+    const int l = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const LevelDesc& lv = od.lv[l];
+    const uint8_t* img = lv.img + b * lv.frame_stride;
+    const int ncand = min((int)od.cnt[b * od.L + l], lv.cand_cap);
+    const uint32_t* cand = lv.cand + (size_t)b * lv.cand_cap;
+    uint32_t* candA = lv.candA + (size_t)b * lv.cand_cap;
+    float* respA = lv.respA + (size_t)b * lv.cand_cap;
+    uint2* surv = reinterpret_cast<uint2*>(dyn);
+    const int nf = lv.nfeat;
+    const bool harris = od.score_type == 0;
+    const int n1 = harris ? 2 * nf : nf; // first retainBest budget (by FAST score)
+
+    if (tid < 256) s_hist[tid] = od.hist[((size_t)b * od.L + l) * 256 + tid];
+    if (tid == 0) { s_nA = 0; s_nS = 0; }
+    __syncthreads();
+    if (tid == 0) {
+        // retainBest(n1) as a set: keep score s iff #(score > s) < n1; n1 == 0 clears
+        int T = 256, gt = 0;
+        if (n1 > 0)
+            for (int s = 255; s >= 0; s--) { if (gt >= n1) break; T = s; gt += (int)s_hist[s]; }
+        s_T = T;
+    }
+    __syncthreads();
+    const int T = s_T;
+    // compact the kept candidates (unordered; order is restored by the final rank sort)
+    for (int i0 = 0; i0 < ncand; i0 += SEL_THREADS) {
+        int i = i0 + tid;
+        uint32_t c = i < ncand ? cand[i] : 0;
+        bool keep = i < ncand && (int)(c >> 24) >= T;
+        unsigned long long bal = __ballot(keep);
+        int base = 0;
+        if ((tid & 63) == 0 && bal) base = atomicAdd(&s_nA, __popcll(bal));
+        base = __shfl(base, 0);
+        if (keep) candA[base + __popcll(bal & ((1ull << (tid & 63)) - 1ull))] = c;
+    }
+    __syncthreads();
+    const int nA = s_nA;
+    for (int i = tid; i < nA; i += SEL_THREADS) {
+        uint32_t c = candA[i];
+        respA[i] = harris ? harris_response(img, lv.pitch, (int)(c & 0xFFF), (int)((c >> 12) & 0xFFF)) : (float)(c >> 24);
+    }
+    __syncthreads();
+    // second retainBest(nf) by response: radix-select the nf-th largest key, keep key >= it
+    uint32_t Tkey = 0; // keep everything
+    if (harris && nf > 0 && nA > nf) {
+        if (tid == 0) { s_prefix = 0; s_mask = 0; s_k = nf; }
+        __syncthreads();
+        for (int shift = 24; shift >= 0; shift -= 8) {
+            if (tid < 256) s_hist[tid] = 0;
+            __syncthreads();
+            const uint32_t prefix = s_prefix, mask = s_mask;
+            for (int i = tid; i < nA; i += SEL_THREADS) {
+                uint32_t k = float_key(respA[i]);
+                if ((k & mask) == prefix) atomicAdd(&s_hist[(k >> shift) & 255], 1u);
+            }
+            __syncthreads();
+            if (tid == 0) {
+                int k = s_k, bin = 255;
+                for (; bin > 0; bin--) { if ((int)s_hist[bin] >= k) break; k -= (int)s_hist[bin]; }
+                s_k = k; s_prefix = prefix | ((uint32_t)bin << shift); s_mask = mask | (255u << shift);
+            }
+            __syncthreads();
+        }
+        Tkey = s_prefix;
+    }
+    const bool clear_all = (nf == 0) || (harris && n1 == 0);
+    // survivors -> LDS
+    for (int i0 = 0; i0 < nA; i0 += SEL_THREADS) {
+        int i = i0 + tid;
+        float r = i < nA ? respA[i] : 0.f;
+        bool keep = i < nA && !clear_all && float_key(r) >= Tkey;
+        unsigned long long bal = __ballot(keep);
+        int base = 0;
+        if ((tid & 63) == 0 && bal) base = atomicAdd(&s_nS, __popcll(bal));
+        base = __shfl(base, 0);
+        int pos = base + __popcll(bal & ((1ull << (tid & 63)) - 1ull));
+        if (keep && pos < od.max_kpts) surv[pos] = make_uint2(candA[i] & 0xFFFFFFu, __float_as_uint(r));
+    }
+    __syncthreads();
+    const int nS = s_nS;
+    if (nS > od.max_kpts) { // response ties overflow the per-frame capacity
+        if (tid == 0) { od.sel_cnt[b * od.L + l] = 0; atomicMin(&od.frame_status[b], (int)MSLAM_ERR_CAPACITY); }
+        return;
+    }
+    // rank sort by key = y<<12 | x (unique) -> row-major order inside the level
+    uint2* out = od.sel + ((size_t)b * od.L + l) * od.max_kpts;
+    for (int i = tid; i < nS; i += SEL_THREADS) {
+        uint2 me = surv[i];
+        int rank = 0;
+        for (int j = 0; j < nS; j++) rank += surv[j].x < me.x;
+        out[rank] = me;
+    }
+    if (tid == 0) od.sel_cnt[b * od.L + l] = nS;
+}
+
+// ---------------------------------------------------------------- K4-K6: describe
+constexpr int DP_R = 21;               // raw patch radius: 18 (pattern reach) + 3 (blur)
+constexpr int DP_N = 2 * DP_R + 1;     // 43
+constexpr int DP_PITCH = 48;           // LDS bytes per raw row (12 dwords)
+constexpr int DB_N = 37;               // blurred patch side (radius 18)
+constexpr int DB_PITCH = 40;
+constexpr int DESC_WAVES = 4;
+
+__device__ __forceinline__ float fast_atan2_deg(float y, float x)
+{
+    const float p1 = 0.9997878412794807f * (float)(180 / 3.1415926535897932384626433832795);
+    const float p3 = -0.3258083974640975f * (float)(180 / 3.1415926535897932384626433832795);
+    const float p5 = 0.1555786518463281f * (float)(180 / 3.1415926535897932384626433832795);
+    const float p7 = -0.04432655554792128f * (float)(180 / 3.1415926535897932384626433832795);
+    float ax = fabsf(x), ay = fabsf(y);
+    float a, c, c2;
+    if (ax >= ay) {
+        c = ay / (ax + (float)2.2204460492503131e-16);
+        c2 = c * c;
+        a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    } else {
+        c = ax / (ay + (float)2.2204460492503131e-16);
+        c2 = c * c;
+        a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    }
+    if (x < 0) a = 180.f - a;
+    if (y < 0) a = 360.f - a;
+    return a;
+}
+
+struct DescArgs {
+    mslam_keypoint* kps; uint8_t* desc; int32_t* n_out; int32_t* status; int cap;
+};
+
+__global__ __launch_bounds__(64 * DESC_WAVES)
+void describe_k(OrbDev od, DescArgs out)
+{
+    __shared__ uint32_t s_raw[DESC_WAVES][DP_N * DP_PITCH / 4];
+    __shared__ uint16_t s_h[DESC_WAVES][DP_N * DB_PITCH];
+    __shared__ uint8_t s_blur[DESC_WAVES][DB_N * DB_PITCH];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int b = blockIdx.y;
+    const int g = blockIdx.x * DESC_WAVES + wave; // keypoint index inside the frame
+    // level offsets (<= 16 counts)
+    int total = 0, l = -1, off = 0;
+    for (int i = 0; i < od.L; i++) {
+        int c = od.sel_cnt[b * od.L + i];
+        if (l < 0 && g < total + c) { l = i; off = total; }
+        total += c;
+    }
+    const int st = od.frame_status[b];
+    const bool bad = st != MSLAM_OK || total > out.cap;
+    if (g == 0 && lane == 0) {
+        out.n_out[b] = bad ? 0 : total;
+        if (out.status) out.status[b] = bad ? (int)MSLAM_ERR_CAPACITY : (int)MSLAM_OK;
+    }
+    const bool active = !bad && l >= 0; // wave-uniform; inactive waves still reach the barriers
+    if (l < 0) l = 0;
+    const LevelDesc& lv = od.lv[l];
+    const uint2 sel = active ? od.sel[((size_t)b * od.L + l) * od.max_kpts + (g - off)] : make_uint2((DP_R << 12) | DP_R, 0);
+    const int x = (int)(sel.x & 0xFFF), y = (int)(sel.x >> 12);
+    const uint8_t* img = lv.img + b * lv.frame_stride;
+    // ---- raw 43x43 patch via aligned dword loads (always inside the image: edge >= 22)
+    const int px0 = x - DP_R, py0 = y - DP_R;
+    const int xa = px0 & ~3, xo = px0 & 3;
+    const int max_dw = lv.pitch / 4 - 1;
+    uint32_t* raw32 = s_raw[wave];
+    for (int i = lane; i < DP_N * (DP_PITCH / 4); i += 64) {
+        int r = i / (DP_PITCH / 4), c = i % (DP_PITCH / 4);
+        raw32[i] = active ? reinterpret_cast<const uint32_t*>(img + (size_t)(py0 + r) * lv.pitch)[min(xa / 4 + c, max_dw)] : 0u;
+    }
+    __syncthreads();
+    const uint8_t* raw = reinterpret_cast<const uint8_t*>(raw32) + xo; // raw[r*DP_PITCH + c], centre at (21,21)
+    // ---- IC_Angle: lane v+15 sums row v of the circular patch
+    int m10 = 0, m01 = 0;
+    if (lane < 31) {
+        int v = lane - 15;
+        int dmax = c_umax[abs(v)];
+        const uint8_t* row = raw + (DP_R + v) * DP_PITCH + DP_R;
+        int rs = 0;
+        for (int u = -dmax; u <= dmax; u++) { int val = row[u]; m10 += u * val; rs += val; }
+        m01 = v * rs;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { m10 += __shfl_xor(m10, o); m01 += __shfl_xor(m01, o); }
+    const float angle = fast_atan2_deg((float)m01, (float)m10);
+    // ---- separable 7x7 Gaussian of the patch: rows (43 x 37) then columns (37 x 37)
+    uint16_t* hbuf = s_h[wave];
+    for (int i = lane; i < DP_N * DB_N; i += 64) {
+        int r = i / DB_N, c = i % DB_N; // output column c <-> raw column c+3 (centre), taps c..c+6
+        const uint8_t* p = raw + r * DP_PITCH + c;
+        int acc = 0;
+#pragma unroll
+        for (int j = 0; j < 7; j++) acc += c_gk[j] * p[j];
+        hbuf[r * DB_PITCH + c] = (uint16_t)acc; // <= 257*255 = 65535
+    }
+    __syncthreads();
+    uint8_t* blur = s_blur[wave];
+    for (int i = lane; i < DB_N * DB_N; i += 64) {
+        int r = i / DB_N, c = i % DB_N;
+        int acc = 0;
+#pragma unroll
+        for (int j = 0; j < 7; j++) acc += c_gk[j] * (int)hbuf[(r + j) * DB_PITCH + c];
+        int v = (acc + (1 << 15)) >> 16;
+        blur[r * DB_PITCH + c] = (uint8_t)(v > 255 ? 255 : v);
+    }
+    __syncthreads();
+    // ---- 256 rotated binary tests; test t = j*64 + lane, ballot j = descriptor bytes 8j..8j+7
+    float ang = angle;
+    ang *= (float)(3.1415926535897932384626433832795 / 180.f);
+    const float ca = (float)cos((double)ang), sb = (float)sin((double)ang);
+    const uint8_t* centre = blur + 18 * DB_PITCH + 18;
+    unsigned long long bits[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int8_t* pt = c_pattern + (j * 64 + lane) * 4;
+        float x0 = pt[0] * ca - pt[1] * sb, y0 = pt[0] * sb + pt[1] * ca;
+        float x1 = pt[2] * ca - pt[3] * sb, y1 = pt[2] * sb + pt[3] * ca;
+        int t0 = centre[__float2int_rn(y0) * DB_PITCH + __float2int_rn(x0)];
+        int t1 = centre[__float2int_rn(y1) * DB_PITCH + __float2int_rn(x1)];
+        bits[j] = __ballot(t0 < t1);
+    }
+    if (!active) return;
+    if (lane < 4) {
+        unsigned long long v = lane == 0 ? bits[0] : lane == 1 ? bits[1] : lane == 2 ? bits[2] : bits[3];
+        reinterpret_cast<unsigned long long*>(out.desc + ((size_t)b * out.cap + g) * 32)[lane] = v;
+    }
+    if (lane == 0) {
+        // coordinates: detect() scales level coordinates by sf, compute() scales by 1/sf, describes at
+        // cvRound() of that (== x, y) and scales by sf again -- three float products (ORB::operator())
+        float fx = (float)x, fy = (float)y;
+        if (l != 0) {
+            fx *= lv.sf; fy *= lv.sf;
+            fx *= lv.inv_sf; fy *= lv.inv_sf;
+            fx *= lv.sf; fy *= lv.sf;
+        }
+        mslam_keypoint k;
+        k.x = fx; k.y = fy; k.size = 31 * lv.sf; k.angle = angle;
+        k.response = __uint_as_float(sel.y); k.octave = l;
+        out.kps[(size_t)b * out.cap + g] = k;
+    }
+}
+
+// standalone full-image blur (test hook / K5): same taps, BORDER_REFLECT_101
+__device__ __forceinline__ int reflect101(int p, int len)
+{
+    if (len == 1) return 0;
+    while ((unsigned)p >= (unsigned)len) p = p < 0 ? -p : 2 * (len - 1) - p;
+    return p;
+}
+__global__ void blur7_k(const uint8_t* __restrict__ src, int w, int h, int pitch, uint8_t* __restrict__ dst)
+{
+    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= w) return;
+    int acc = 0;
+    for (int j = 0; j < 7; j++) {
+        const uint8_t* r = src + (size_t)reflect101(y + j - 3, h) * pitch;
+        int hacc = 0;
+        for (int i = 0; i < 7; i++) hacc += c_gk[i] * r[reflect101(x + i - 3, w)];
+        acc += c_gk[j] * hacc;
+    }
+    int v = (acc + (1 << 15)) >> 16;
+    dst[(size_t)y * w + x] = (uint8_t)(v > 255 ? 255 : v);
+}
+
+inline int cv_round_host(double v) { return (int)std::lrint(v); }
+inline int cv_floor_host(double v) { int i = (int)v; return i - (i > v); }
+inline int sat_short_host(int v) { return v < -32768 ? -32768 : v > 32767 ? 32767 : v; }
+
+} // namespace
+
+// geometry-dependent plan: level sizes, resize tables, scratch buffers
+struct OrbPlan {
+    int w = 0, h = 0, B = 0, channels = 0;
+    mslam_orb_params prm{};
+    OrbDev dev{};
+    void* arena = nullptr;     // one allocation for everything below
+    size_t arena_bytes = 0;
+    uint8_t* level0 = nullptr; // internal level-0 buffer (BGR input or unaligned gray)
+    int level0_pitch = 0;
+    long long level0_fstride = 0;
+    uint8_t* last_l0 = nullptr; int last_l0_pitch = 0;      // level 0 of the last call (may alias caller memory)
+    uint32_t* counters = nullptr; size_t counters_bytes = 0; // hist + cnt + sel_cnt + frame_status (zeroed per batch)
+};
+
+void orb_plan_destroy(mslam_ctx* ctx)
+{
+    if (!ctx->orb) return;
+    if (ctx->orb->arena) (void)hipFree(ctx->orb->arena);
+    delete ctx->orb;
+    ctx->orb = nullptr;
+}
+
+static bool same_params(const mslam_orb_params& a, const mslam_orb_params& b)
+{
+    return a.nfeatures == b.nfeatures && a.scale_factor == b.scale_factor && a.nlevels == b.nlevels &&
+           a.edge_threshold == b.edge_threshold && a.first_level == b.first_level && a.wta_k == b.wta_k &&
+           a.score_type == b.score_type && a.patch_size == b.patch_size && a.fast_threshold == b.fast_threshold;
+}
+
+static int orb_plan_get(mslam_ctx* ctx, int w, int h, int B, int channels, const mslam_orb_params* p, OrbPlan** out)
+{
+    if (ctx->orb && ctx->orb->w == w && ctx->orb->h == h && ctx->orb->B >= B && ctx->orb->channels == channels &&
+        same_params(ctx->orb->prm, *p)) {
+        *out = ctx->orb;
+        return MSLAM_OK;
+    }
+    if (p->nlevels < 1 || p->nlevels > MSLAM_MAX_LEVELS || p->first_level != 0 || p->wta_k != 2 || p->patch_size != 31 ||
+        !(p->scale_factor > 1.0f) || p->edge_threshold < 22 || p->edge_threshold > 255 || p->nfeatures < 0 ||
+        p->fast_threshold < 1 || p->fast_threshold > 254 || (p->score_type != 0 && p->score_type != 1))
+        return MSLAM_ERR_INVALID;
+    if (w > ctx->max_w || h > ctx->max_h || B > ctx->batch) return MSLAM_ERR_CAPACITY;
+    MSLAM_TRY(ctx_set_device(ctx));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    orb_plan_destroy(ctx);
+    OrbPlan* pl = new OrbPlan();
+    ctx->orb = pl;
+    pl->w = w; pl->h = h; pl->B = B; pl->channels = channels; pl->prm = *p;
+    OrbDev& od = pl->dev;
+    od.L = p->nlevels; od.B = B; od.edge = p->edge_threshold;
+    od.max_kpts = ctx->max_kpts < SEL_LEVEL_CAP ? ctx->max_kpts : SEL_LEVEL_CAP; // per-level list capacity
+    od.fast_thr = p->fast_threshold; od.score_type = p->score_type;
+    const int L = od.L, edge = od.edge;
+    // level geometry and feature budget -- ORB::operator() / computeKeyPoints (OpenCV 2.4.13)
+    const double scaleFactor = (double)p->scale_factor;
+    {
+        float factor = (float)(1.0 / scaleFactor);
+        float nd = p->nfeatures * (1 - factor) / (1 - (float)std::pow((double)factor, (double)L));
+        int sum = 0;
+        for (int l = 0; l < L - 1; l++) {
+            od.lv[l].nfeat = cv_round_host(nd);
+            sum += od.lv[l].nfeat;
+            nd *= factor;
+        }
+        od.lv[L - 1].nfeat = p->nfeatures - sum > 0 ? p->nfeatures - sum : 0;
+    }
+    size_t bytes = 0;
+    auto reserve = [&](size_t n) { bytes = align_up(bytes, 256); size_t o = bytes; bytes += n; return o; };
+    size_t off_img[MSLAM_MAX_LEVELS], off_cand[MSLAM_MAX_LEVELS], off_candA[MSLAM_MAX_LEVELS], off_resp[MSLAM_MAX_LEVELS],
+        off_xt[MSLAM_MAX_LEVELS], off_yt[MSLAM_MAX_LEVELS];
+    int tile_base = 0;
+    for (int l = 0; l < L; l++) {
+        LevelDesc& lv = od.lv[l];
+        float s = (float)std::pow(scaleFactor, (double)l);
+        float inv = 1 / s;
+        lv.sf = s; lv.inv_sf = inv;
+        lv.w = cv_round_host(w * inv); lv.h = cv_round_host(h * inv);
+        if (lv.w < 1 || lv.h < 1) return MSLAM_ERR_INVALID;
+        lv.pitch = (int)align_up((size_t)lv.w, 64);
+        lv.frame_stride = (long long)lv.pitch * lv.h;
+        off_img[l] = reserve((size_t)lv.frame_stride * B);
+        lv.roi_x0 = edge; lv.roi_y0 = edge;
+        lv.roi_w = lv.w - 2 * edge; lv.roi_h = lv.h - 2 * edge;
+        if (lv.roi_w <= 0 || lv.roi_h <= 0) { lv.roi_w = 0; lv.roi_h = 0; }
+        lv.tiles_x = (lv.roi_w + FT_W - 1) / FT_W; lv.tiles_y = (lv.roi_h + FT_H - 1) / FT_H;
+        lv.tile_base = tile_base;
+        tile_base += lv.tiles_x * lv.tiles_y;
+        lv.cand_cap = ((lv.roi_w + 1) / 2) * ((lv.roi_h + 1) / 2) + 1;
+        off_cand[l] = reserve(sizeof(uint32_t) * (size_t)lv.cand_cap * B);
+        off_candA[l] = reserve(sizeof(uint32_t) * (size_t)lv.cand_cap * B);
+        off_resp[l] = reserve(sizeof(float) * (size_t)lv.cand_cap * B);
+        off_xt[l] = reserve(sizeof(int4) * (size_t)lv.w);
+        off_yt[l] = reserve(sizeof(int4) * (size_t)lv.h);
+    }
+    od.tiles_per_frame = tile_base;
+    const size_t off_sel = reserve(sizeof(uint2) * (size_t)B * L * od.max_kpts);
+    const size_t n_hist = (size_t)B * L * 256, n_cnt = (size_t)B * L;
+    pl->counters_bytes = sizeof(uint32_t) * (n_hist + 2 * n_cnt + B);
+    const size_t off_cnt = reserve(pl->counters_bytes);
+    HIP_TRY(ctx, hipMalloc(&pl->arena, bytes));
+    pl->arena_bytes = bytes;
+    char* base = (char*)pl->arena;
+    pl->counters = (uint32_t*)(base + off_cnt);
+    od.hist = pl->counters;
+    od.cnt = od.hist + n_hist;
+    od.sel_cnt = (int32_t*)(od.cnt + n_cnt);
+    od.frame_status = od.sel_cnt + n_cnt;
+    od.sel = (uint2*)(base + off_sel);
+    std::vector<int4> tab;
+    for (int l = 0; l < L; l++) {
+        LevelDesc& lv = od.lv[l];
+        lv.img = (uint8_t*)(base + off_img[l]);
+        lv.cand = (uint32_t*)(base + off_cand[l]);
+        lv.candA = (uint32_t*)(base + off_candA[l]);
+        lv.respA = (float*)(base + off_resp[l]);
+        lv.xtab = (int4*)(base + off_xt[l]);
+        lv.ytab = (int4*)(base + off_yt[l]);
+        if (l == 0) continue;
+        // resize(INTER_LINEAR) coefficient tables for level l-1 -> l (OpenCV 2.4.13 imgwarp.cpp)
+        const int sw = od.lv[l - 1].w, sh = od.lv[l - 1].h, dw = lv.w, dh = lv.h;
+        const double inv_scale_x = (double)dw / sw, inv_scale_y = (double)dh / sh;
+        const double scale_x = 1. / inv_scale_x, scale_y = 1. / inv_scale_y;
+        tab.assign((size_t)dw, make_int4(0, 0, 0, 0));
+        for (int dx = 0; dx < dw; dx++) {
+            float fx = (float)((dx + 0.5) * scale_x - 0.5);
+            int sx = cv_floor_host(fx);
+            fx -= sx;
+            if (sx < 0) { fx = 0; sx = 0; }
+            if (sx >= sw - 1) { fx = 0; sx = sw - 1; }
+            tab[dx] = make_int4(sx, sx + 1 < sw ? sx + 1 : sx, sat_short_host(cv_round_host((1.f - fx) * 2048)),
+                                sat_short_host(cv_round_host(fx * 2048)));
+        }
+        HIP_TRY(ctx, hipMemcpy(lv.xtab, tab.data(), sizeof(int4) * (size_t)dw, hipMemcpyHostToDevice));
+        tab.assign((size_t)dh, make_int4(0, 0, 0, 0));
+        for (int dy = 0; dy < dh; dy++) {
+            float fy = (float)((dy + 0.5) * scale_y - 0.5);
+            int sy = cv_floor_host(fy);
+            fy -= sy;
+            int s0 = sy < 0 ? 0 : (sy < sh ? sy : sh - 1);
+            int s1 = sy + 1 < 0 ? 0 : (sy + 1 < sh ? sy + 1 : sh - 1);
+            tab[dy] = make_int4(s0, s1, sat_short_host(cv_round_host((1.f - fy) * 2048)),
+                                sat_short_host(cv_round_host(fy * 2048)));
+        }
+        HIP_TRY(ctx, hipMemcpy(lv.ytab, tab.data(), sizeof(int4) * (size_t)dh, hipMemcpyHostToDevice));
+    }
+    pl->level0 = od.lv[0].img;
+    pl->level0_pitch = od.lv[0].pitch;
+    pl->level0_fstride = od.lv[0].frame_stride;
+    *out = pl;
+    return MSLAM_OK;
+}
+
+extern "C" {
+
+void mslam_orb_default_params(mslam_orb_params* p)
+{
+    if (!p) return;
+    p->nfeatures = 500; p->scale_factor = 1.2f; p->nlevels = 8; p->edge_threshold = 31; p->first_level = 0;
+    p->wta_k = 2; p->score_type = 0; p->patch_size = 31; p->fast_threshold = 20;
+}
+
+int mslam_orb_extract_batch_dev(mslam_ctx* ctx, const uint8_t* imgs, int B, int w, int h, int stride,
+                                int64_t frame_stride, int channels, const mslam_orb_params* params,
+                                mslam_keypoint* kps, uint8_t* desc, int cap, int32_t* n_out, int32_t* status_dev)
+{
+    if (!ctx || !imgs || !params || !kps || !desc || !n_out || B < 1 || w < 16 || h < 16 || cap < 1 ||
+        (channels != 1 && channels != 3 && channels != 4) || stride < w * channels || frame_stride < (int64_t)stride * h)
+        return MSLAM_ERR_INVALID;
+    if (((uintptr_t)desc & 7) || ((uintptr_t)kps & 3)) return MSLAM_ERR_INVALID;
+    OrbPlan* pl = nullptr;
+    MSLAM_TRY(orb_plan_get(ctx, w, h, B, channels, params, &pl));
+    OrbDev od = pl->dev;
+    od.B = B;
+    hipStream_t st = ctx->stream;
+    // level 0: alias the caller's gray frames when dword loads are legal on them, else convert/copy
+    const bool alias = channels == 1 && ((uintptr_t)imgs & 3) == 0 && (stride & 3) == 0 && (frame_stride & 3) == 0;
+    if (alias) {
+        od.lv[0].img = const_cast<uint8_t*>(imgs);
+        od.lv[0].pitch = stride;
+        od.lv[0].frame_stride = frame_stride;
+    } else {
+        od.lv[0].img = pl->level0; od.lv[0].pitch = pl->level0_pitch; od.lv[0].frame_stride = pl->level0_fstride;
+        hipLaunchKernelGGL(bgr2gray_k, dim3((w + 255) / 256, h, B), dim3(256), 0, st, imgs, w, h, stride,
+                           (long long)frame_stride, channels, od.lv[0].img, od.lv[0].pitch, od.lv[0].frame_stride);
+    }
+    pl->last_l0 = od.lv[0].img; pl->last_l0_pitch = od.lv[0].pitch;
+    HIP_TRY(ctx, hipMemsetAsync(pl->counters, 0, pl->counters_bytes, st));
+    for (int l = 1; l < od.L; l++) {
+        const LevelDesc& s = od.lv[l - 1];
+        const LevelDesc& d = od.lv[l];
+        hipLaunchKernelGGL(resize_k, dim3((d.w + 1023) / 1024, d.h, B), dim3(256), 0, st, s.img, s.pitch, s.frame_stride,
+                           d.img, d.w, d.h, d.pitch, d.frame_stride, d.xtab, d.ytab);
+    }
+    if (od.tiles_per_frame > 0)
+        hipLaunchKernelGGL(fast_nms_k, dim3(od.tiles_per_frame * B), dim3(FAST_THREADS), 0, st, od);
+    hipLaunchKernelGGL(select_k, dim3(od.L, B), dim3(SEL_THREADS), sizeof(uint2) * (size_t)od.max_kpts, st, od);
+    DescArgs da{ kps, desc, n_out, status_dev, cap };
+    const int max_total = cap < od.max_kpts * od.L ? cap : od.max_kpts * od.L;
+    hipLaunchKernelGGL(describe_k, dim3((max_total + DESC_WAVES - 1) / DESC_WAVES + 1, B), dim3(64 * DESC_WAVES), 0, st, od, da);
+    HIP_TRY(ctx, hipGetLastError());
+    return MSLAM_OK;
+}
+
+int mslam_orb_extract(mslam_ctx* ctx, const uint8_t* img, int w, int h, int stride, int channels,
+                      const mslam_orb_params* params, mslam_keypoint* kps, uint8_t* desc, int cap, int* n_out)
+{
+    if (!ctx || !img || !params || !kps || !desc || !n_out || cap < 1 || w < 16 || h < 16 || stride < w * channels)
+        return MSLAM_ERR_INVALID;
+    MSLAM_TRY(ctx_set_device(ctx));
+    const size_t img_bytes = align_up((size_t)stride * h, 256);
+    size_t bytes = img_bytes + align_up(sizeof(mslam_keypoint) * (size_t)cap, 256) + align_up((size_t)cap * 32, 256) + 512;
+    void* stg = nullptr;
+    MSLAM_TRY(ctx_stage(ctx, bytes, &stg));
+    Bump bp{ (char*)stg, 0, bytes };
+    uint8_t* dimg = bp.take<uint8_t>(img_bytes);
+    mslam_keypoint* dk = bp.take<mslam_keypoint>(cap);
+    uint8_t* dd = bp.take<uint8_t>((size_t)cap * 32);
+    int32_t* dn = bp.take<int32_t>(2);
+    HIP_TRY(ctx, hipMemcpyAsync(dimg, img, (size_t)stride * h, hipMemcpyHostToDevice, ctx->stream));
+    MSLAM_TRY(mslam_orb_extract_batch_dev(ctx, dimg, 1, w, h, stride, (int64_t)img_bytes, channels, params, dk, dd, cap, dn, dn + 1));
+    int32_t hn[2] = { 0, 0 };
+    HIP_TRY(ctx, hipMemcpyAsync(hn, dn, sizeof(hn), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (hn[1] != MSLAM_OK) { *n_out = 0; return hn[1]; }
+    *n_out = hn[0];
+    if (hn[0] > 0) {
+        HIP_TRY(ctx, hipMemcpyAsync(kps, dk, sizeof(mslam_keypoint) * (size_t)hn[0], hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(desc, dd, (size_t)hn[0] * 32, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return MSLAM_OK;
+}
+
+int mslam_orb_debug_level(mslam_ctx* ctx, int level, int blurred, uint8_t* out, int* level_w, int* level_h)
+{
+    if (!ctx || !ctx->orb || !out || !level_w || !level_h || level < 0 || level >= ctx->orb->dev.L) return MSLAM_ERR_INVALID;
+    MSLAM_TRY(ctx_set_device(ctx));
+    OrbPlan* pl = ctx->orb;
+    LevelDesc lv = pl->dev.lv[level];
+    if (level == 0 && pl->last_l0) { lv.img = pl->last_l0; lv.pitch = pl->last_l0_pitch; }
+    *level_w = lv.w; *level_h = lv.h;
+    if (!blurred) {
+        HIP_TRY(ctx, hipMemcpy2DAsync(out, lv.w, lv.img, lv.pitch, lv.w, lv.h, hipMemcpyDeviceToHost, ctx->stream));
+    } else {
+        void* scr = nullptr;
+        MSLAM_TRY(ctx_scratch(ctx, (size_t)lv.w * lv.h, &scr));
+        hipLaunchKernelGGL(blur7_k, dim3((lv.w + 255) / 256, lv.h), dim3(256), 0, ctx->stream, lv.img, lv.w, lv.h, lv.pitch, (uint8_t*)scr);
+        HIP_TRY(ctx, hipMemcpyAsync(out, scr, (size_t)lv.w * lv.h, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return MSLAM_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,143 @@
+"""ctypes binding of liboracle.so -- TEST INFRASTRUCTURE ONLY (see oracle.h).
+
+Imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg; never by the
+product package.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+u8p = C.POINTER(C.c_uint8)
+i32p = C.POINTER(C.c_int32)
+f32p = C.POINTER(C.c_float)
+f64p = C.POINTER(C.c_double)
+
+
+class OrbParams(C.Structure):
+    _fields_ = [("nfeatures", C.c_int), ("scale_factor", C.c_float), ("nlevels", C.c_int),
+                ("edge_threshold", C.c_int), ("first_level", C.c_int), ("wta_k", C.c_int),
+                ("score_type", C.c_int), ("patch_size", C.c_int), ("fast_threshold", C.c_int)]
+
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
+                     ("octave", "<i4")])
+
+
+class FmatParams(C.Structure):
+    _fields_ = [("metric", C.c_int), ("threshold", C.c_double), ("confidence", C.c_double), ("refit", C.c_int)]
+
+
+class PnpParams(C.Structure):
+    _fields_ = [("reproj_thr", C.c_double), ("confidence", C.c_double), ("refine_iters", C.c_int),
+                ("min_inliers", C.c_int)]
+
+
+class BaProblem(C.Structure):
+    _fields_ = [("n_poses", C.c_int), ("n_points", C.c_int), ("n_edges", C.c_int),
+                ("poses", f64p), ("pose_fixed", u8p), ("points", f64p),
+                ("edge_pose", i32p), ("edge_point", i32p), ("obs", f64p), ("info", f64p),
+                ("intr", f64p), ("huber_delta", C.c_double)]
+
+
+class BaSystem(C.Structure):
+    _fields_ = [("err", f64p), ("chi2", f64p), ("rho1", f64p), ("Hpp", f64p), ("Hll", f64p),
+                ("Hpl_rowptr", i32p), ("Hpl_col", i32p), ("Hpl_val", f64p), ("b", f64p),
+                ("robust_chi2", C.c_double), ("n_free_poses", C.c_int), ("nnzb", C.c_int)]
+
+
+def build(force: bool = False) -> str:
+    """Compile liboracle.so with gcc (the checker; building it is not using it)."""
+    so = os.path.join(_HERE, "liboracle.so")
+    srcs = [f for f in os.listdir(_HERE) if f.endswith((".c", ".h", ".inc"))]
+    newest = max(os.path.getmtime(os.path.join(_HERE, f)) for f in srcs)
+    if force or not os.path.exists(so) or os.path.getmtime(so) < newest:
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return so
+
+
+def lib() -> C.CDLL:
+    global _LIB
+    if _LIB is None:
+        so = os.path.join(_HERE, "liboracle.so")
+        if not os.path.exists(so):
+            build()
+        _LIB = C.CDLL(so)
+        _LIB.orc_harris_response.restype = C.c_float
+        _LIB.orc_ic_angle.restype = C.c_float
+        _LIB.orc_fast_atan2.restype = C.c_float
+        _LIB.orc_fast_atan2.argtypes = [C.c_float, C.c_float]
+        for name in ("orc_det3", "orc_fmat_error"):
+            if hasattr(_LIB, name):
+                getattr(_LIB, name).restype = C.c_double
+    return _LIB
+
+
+def _p(a, t):
+    return a.ctypes.data_as(t)
+
+
+def orb_default_params(nfeatures: int = 500) -> OrbParams:
+    p = OrbParams()
+    lib().orc_orb_default_params(C.byref(p))
+    p.nfeatures = nfeatures
+    return p
+
+
+def orb_level_sizes(w, h, params):
+    L = params.nlevels
+    lw = np.zeros(L, np.int32); lh = np.zeros(L, np.int32); nf = np.zeros(L, np.int32)
+    sf = np.zeros(L, np.float32); inv = np.zeros(L, np.float32)
+    lib().orc_orb_level_sizes(w, h, C.byref(params), _p(lw, i32p), _p(lh, i32p), _p(sf, f32p), _p(inv, f32p), _p(nf, i32p))
+    return lw, lh, sf, inv, nf
+
+
+def orb_extract(img: np.ndarray, params: OrbParams, cap: int | None = None):
+    img = np.ascontiguousarray(img)
+    h, w = img.shape[:2]
+    ch = 1 if img.ndim == 2 else img.shape[2]
+    if cap is None:
+        cap = params.nfeatures * 2 + 256
+    kps = np.zeros(cap, dtype=KP_DTYPE)
+    desc = np.zeros((cap, 32), dtype=np.uint8)
+    n = C.c_int(0)
+    rc = lib().orc_orb_extract(_p(img, u8p), w, h, w * ch, ch, C.byref(params), kps.ctypes.data_as(C.c_void_p),
+                               _p(desc, u8p), cap, C.byref(n))
+    if rc != 0:
+        raise RuntimeError(f"orc_orb_extract rc={rc}")
+    return kps[: n.value].copy(), desc[: n.value].copy()
+
+
+def orb_level(img: np.ndarray, params: OrbParams, level: int, blurred: bool):
+    img = np.ascontiguousarray(img)
+    h, w = img.shape[:2]
+    ch = 1 if img.ndim == 2 else img.shape[2]
+    out = np.zeros(w * h, dtype=np.uint8)
+    lw, lh = C.c_int(0), C.c_int(0)
+    rc = lib().orc_orb_level(_p(img, u8p), w, h, w * ch, ch, C.byref(params), level, int(blurred), _p(out, u8p),
+                             C.byref(lw), C.byref(lh))
+    if rc != 0:
+        raise RuntimeError(f"orc_orb_level rc={rc}")
+    return out[: lw.value * lh.value].reshape(lh.value, lw.value).copy()
+
+
+def match_knn2(q: np.ndarray, t: np.ndarray):
+    q = np.ascontiguousarray(q, dtype=np.uint8); t = np.ascontiguousarray(t, dtype=np.uint8)
+    nq, nt = q.shape[0], t.shape[0]
+    idx = np.zeros((nq, 2), np.int32); dist = np.zeros((nq, 2), np.int32)
+    rc = lib().orc_match_knn2(_p(q, u8p), nq, _p(t, u8p), nt, _p(idx, i32p), _p(dist, i32p))
+    return rc, idx, dist
+
+
+def ratio_filter(idx, dist, ratio: float):
+    nq = idx.shape[0]
+    qi = np.zeros(nq, np.int32); ti = np.zeros(nq, np.int32); d = np.zeros(nq, np.float32)
+    n = C.c_int(0)
+    lib().orc_ratio_filter(_p(idx, i32p), _p(dist, i32p), nq, C.c_float(ratio), _p(qi, i32p), _p(ti, i32p), _p(d, f32p), C.byref(n))
+    return qi[: n.value].copy(), ti[: n.value].copy(), d[: n.value].copy()

@@ -1,0 +1,99 @@
+"""K7 parity: HIP Hamming kNN-2 (through the C ABI) vs the oracle -- bit-exact indices and distances."""
+import numpy as np
+import pytest
+
+from monocular_slam_amd import api, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _check(ctx, oracle, q, t):
+    idx, dist = ctx.match_knn2(q, t)
+    rc, oidx, odist = oracle.match_knn2(q, t)
+    assert rc == 0
+    np.testing.assert_array_equal(idx, oidx)
+    np.testing.assert_array_equal(dist, odist)
+    return idx, dist
+
+
+def test_c1m_2000x2000(ctx, oracle):
+    a, b, perm = synth.descriptor_sets(2000, 2003)
+    idx, dist = _check(ctx, oracle, b, a)
+    # ratio test: same survivors as the oracle, and most true matches recovered
+    for ratio in (0.8, 0.85):
+        qi, ti, d = api.ratio_filter(idx, dist, ratio)
+        oq, ot, od = oracle.ratio_filter(idx, dist, ratio)
+        np.testing.assert_array_equal(qi, oq)
+        np.testing.assert_array_equal(ti, ot)
+        np.testing.assert_array_equal(d, od)
+    assert (perm[qi] == ti).mean() > 0.99
+
+
+@pytest.mark.parametrize("nq,nt", [(1, 2), (2, 2), (63, 65), (64, 64), (257, 255), (513, 700), (500, 3), (3, 1500), (4096, 4096)])
+def test_ragged_sizes(ctx, oracle, nq, nt):
+    rng = np.random.default_rng(nq * 7919 + nt)
+    q = rng.integers(0, 256, size=(nq, 32), dtype=np.uint8)
+    t = rng.integers(0, 256, size=(nt, 32), dtype=np.uint8)
+    _check(ctx, oracle, q, t)
+
+
+def test_ties_go_to_lower_train_index(ctx, oracle):
+    """Collisions: duplicated train rows and all-equal distances must rank by train index."""
+    rng = np.random.default_rng(5)
+    base = rng.integers(0, 256, size=(40, 32), dtype=np.uint8)
+    t = np.concatenate([base, base, base[::-1]])       # every row appears 3 times
+    q = np.concatenate([base, np.zeros((5, 32), np.uint8), np.full((5, 32), 255, np.uint8)])
+    idx, dist = _check(ctx, oracle, q, t)
+    assert (dist[:40, 0] == 0).all() and (dist[:40, 1] == 0).all()
+    assert (idx[:40, 0] == np.arange(40)).all() and (idx[:40, 1] == np.arange(40) + 40).all()
+    # constant train set: best = row 0, second = row 1
+    t2 = np.zeros((300, 32), np.uint8)
+    idx2, dist2 = _check(ctx, oracle, q, t2)
+    assert (idx2[:, 0] == 0).all() and (idx2[:, 1] == 1).all()
+
+
+def test_too_few_train_rows(ctx):
+    q = np.zeros((4, 32), np.uint8)
+    with pytest.raises(api.MslamError) as e:
+        ctx.match_knn2(q, np.zeros((1, 32), np.uint8))
+    assert e.value.status == api.ERR_TOO_FEW
+    idx, dist = ctx.match_knn2(np.zeros((0, 32), np.uint8), np.zeros((5, 32), np.uint8))
+    assert idx.shape == (0, 2)
+
+
+def test_batched_device_path_with_ratio(ctx, oracle):
+    """Batched device entry point: ragged per-problem counts, fused ratio test and ordered compaction."""
+    B, cap = 5, 700
+    rng = np.random.default_rng(11)
+    nq = np.array([700, 1, 333, 0, 512], np.int32)
+    nt = np.array([650, 700, 2, 100, 1], np.int32)   # last problem has < 2 train rows
+    q = rng.integers(0, 256, size=(B, cap, 32), dtype=np.uint8)
+    t = rng.integers(0, 256, size=(B, cap, 32), dtype=np.uint8)
+    # plant near-duplicates so that the ratio test keeps something
+    for b in range(B):
+        k = min(nq[b], nt[b]) // 2
+        t[b, :k] = q[b, :k]
+        t[b, :k, 0] ^= 1
+    D = api.DevBuf.from_array
+    dq, dt, dnq, dnt = D(ctx, q), D(ctx, t), D(ctx, nq), D(ctx, nt)
+    didx = D(ctx, np.full((B, cap, 2), -7, np.int32))
+    ddist = api.DevBuf(ctx, B * cap * 2 * 4)
+    mq, mt, md = api.DevBuf(ctx, B * cap * 4), api.DevBuf(ctx, B * cap * 4), api.DevBuf(ctx, B * cap * 4)
+    mc = api.DevBuf(ctx, B * 4)
+    ctx.match_knn2_batch_dev(dq.ptr, dnq.ptr, dt.ptr, dnt.ptr, cap, B, didx.ptr, ddist.ptr, 0.8, mq.ptr, mt.ptr, md.ptr, mc.ptr)
+    ctx.sync()
+    idx, dist = didx.download(np.int32, (B, cap, 2)), ddist.download(np.int32, (B, cap, 2))
+    mcount = mc.download(np.int32, (B,))
+    hq, ht, hd = mq.download(np.int32, (B, cap)), mt.download(np.int32, (B, cap)), md.download(np.float32, (B, cap))
+    for b in range(B):
+        if nt[b] < 2:
+            assert mcount[b] == 0 and (idx[b, : nq[b]] == -1).all()
+            continue
+        rc, oidx, odist = oracle.match_knn2(q[b, : nq[b]], t[b, : nt[b]])
+        np.testing.assert_array_equal(idx[b, : nq[b]], oidx)
+        np.testing.assert_array_equal(dist[b, : nq[b]], odist)
+        oq, ot, od = oracle.ratio_filter(oidx, odist, 0.8)
+        assert mcount[b] == len(oq)
+        np.testing.assert_array_equal(hq[b, : mcount[b]], oq)
+        np.testing.assert_array_equal(ht[b, : mcount[b]], ot)
+        np.testing.assert_array_equal(hd[b, : mcount[b]], od)

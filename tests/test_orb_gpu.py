@@ -1,0 +1,112 @@
+"""K1-K6 parity: HIP ORB (through the C ABI) vs the oracle -- bit-exact keypoints and descriptors."""
+import numpy as np
+import pytest
+
+from monocular_slam_amd import api, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _same_keypoints(kg, dg, ko, do):
+    assert len(kg) == len(ko)
+    for f in ("x", "y", "size", "angle", "response", "octave"):
+        np.testing.assert_array_equal(kg[f], ko[f], err_msg=f)
+    np.testing.assert_array_equal(dg, do)
+
+
+def _oracle_params(oracle, p):
+    op = oracle.orb_default_params(p.nfeatures)
+    for f, _ in api.OrbParams._fields_:
+        setattr(op, f, getattr(p, f))
+    return op
+
+
+@pytest.mark.parametrize("w,h,nf,seed", [(640, 480, 500, 1001), (1920, 1080, 2000, 2002), (333, 257, 300, 7), (640, 480, 2000, 1002)])
+def test_extract_bit_exact(ctx, oracle, w, h, nf, seed):
+    img = synth.textured_frame(w, h, seed)
+    p = api.default_orb_params(nf)
+    kg, dg = ctx.orb_extract(img, p)
+    ko, do = oracle.orb_extract(img, _oracle_params(oracle, p), cap=8192)
+    assert len(ko) > nf // 4
+    _same_keypoints(kg, dg, ko, do)
+
+
+def test_pyramid_levels_bit_exact(ctx, oracle):
+    img = synth.textured_frame(640, 480, 1001)
+    p = api.default_orb_params(500)
+    ctx.orb_extract(img, p)
+    op = _oracle_params(oracle, p)
+    for level in range(p.nlevels):
+        g = ctx.orb_debug_level(level, False, 640, 480)
+        o = oracle.orb_level(img, op, level, False)
+        np.testing.assert_array_equal(g, o, err_msg=f"level {level}")
+        gb = ctx.orb_debug_level(level, True, 640, 480)
+        ob = oracle.orb_level(img, op, level, True)
+        np.testing.assert_array_equal(gb, ob, err_msg=f"blurred level {level}")
+
+
+def test_bgr_and_bgra_input(ctx, oracle):
+    rng = np.random.default_rng(3)
+    g = synth.textured_frame(400, 300, 31)
+    bgr = np.stack([g, np.roll(g, 3, axis=1), np.roll(g, 5, axis=0)], axis=2)
+    bgra = np.concatenate([bgr, rng.integers(0, 256, size=(300, 400, 1), dtype=np.uint8)], axis=2)
+    p = api.default_orb_params(400)
+    for im in (bgr, bgra):
+        kg, dg = ctx.orb_extract(np.ascontiguousarray(im), p)
+        ko, do = oracle.orb_extract(np.ascontiguousarray(im), _oracle_params(oracle, p), cap=8192)
+        assert len(ko) > 50
+        _same_keypoints(kg, dg, ko, do)
+
+
+def test_fast_score_mode_and_other_params(ctx, oracle):
+    img = synth.textured_frame(640, 480, 77)
+    for kw in (dict(score_type=1), dict(nlevels=4, scale_factor=1.5), dict(fast_threshold=35, nfeatures=150),
+               dict(edge_threshold=40), dict(nlevels=1)):
+        p = api.default_orb_params(500)
+        for k, v in kw.items():
+            setattr(p, k, v)
+        kg, dg = ctx.orb_extract(img, p)
+        ko, do = oracle.orb_extract(img, _oracle_params(oracle, p), cap=8192)
+        assert len(ko) > 20, kw
+        _same_keypoints(kg, dg, ko, do)
+
+
+def test_flat_and_tiny_frames(ctx, oracle):
+    p = api.default_orb_params(500)
+    flat = np.full((480, 640), 90, np.uint8)
+    kg, dg = ctx.orb_extract(flat, p)
+    assert len(kg) == 0
+    tiny = synth.textured_frame(70, 66, 5)   # most levels are smaller than 2*edge: no keypoints there
+    kg, dg = ctx.orb_extract(tiny, p)
+    ko, do = oracle.orb_extract(tiny, _oracle_params(oracle, p), cap=8192)
+    _same_keypoints(kg, dg, ko, do)
+
+
+def test_response_ties_overflow_is_an_error(ctx, oracle):
+    """A perfect checkerboard makes every corner tie: retainBest keeps them all -> capacity error on both sides."""
+    yy, xx = np.mgrid[0:480, 0:640]
+    board = (((yy // 16) + (xx // 16)) % 2 * 200 + 20).astype(np.uint8)
+    p = api.default_orb_params(50)
+    with pytest.raises(api.MslamError) as e:
+        ctx.orb_extract(board, p, cap=64)
+    assert e.value.status == api.ERR_CAPACITY
+    with pytest.raises(RuntimeError):
+        oracle.orb_extract(board, _oracle_params(oracle, p), cap=64)
+
+
+def test_batched_device_extract(ctx, oracle):
+    B, w, h, cap = 4, 640, 480, 1024
+    frames = np.stack([synth.textured_frame(w, h, 100 + i) for i in range(B)])
+    p = api.default_orb_params(500)
+    dimg = api.DevBuf.from_array(ctx, frames)
+    dk, dd = api.DevBuf(ctx, B * cap * 24), api.DevBuf(ctx, B * cap * 32)
+    dn, ds = api.DevBuf(ctx, B * 4), api.DevBuf(ctx, B * 4)
+    ctx.orb_extract_batch_dev(dimg.ptr, B, w, h, w, w * h, 1, p, dk.ptr, dd.ptr, cap, dn.ptr, ds.ptr)
+    ctx.sync()
+    n = dn.download(np.int32, (B,))
+    assert (ds.download(np.int32, (B,)) == 0).all()
+    kall = dk.download(api.KP_DTYPE, (B, cap))
+    dall = dd.download(np.uint8, (B, cap, 32))
+    for b in range(B):
+        ko, do = oracle.orb_extract(frames[b], _oracle_params(oracle, p), cap=8192)
+        _same_keypoints(kall[b, : n[b]], dall[b, : n[b]], ko, do)
