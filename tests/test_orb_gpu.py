@@ -82,11 +82,16 @@ def test_flat_and_tiny_frames(ctx, oracle):
     _same_keypoints(kg, dg, ko, do)
 
 
-def test_response_ties_overflow_is_an_error(ctx, oracle):
-    """A perfect checkerboard makes every corner tie: retainBest keeps them all -> capacity error on both sides."""
+def test_response_ties_are_all_kept_then_overflow_is_an_error(ctx, oracle):
+    """A grid of identical dots makes 936 level-0 corners tie on FAST score and Harris response:
+    retainBest keeps every tie (n_out > nfeatures); if they do not fit the capacity both sides fail."""
     yy, xx = np.mgrid[0:480, 0:640]
-    board = (((yy // 16) + (xx // 16)) % 2 * 200 + 20).astype(np.uint8)
+    board = np.where(((yy % 16) == 8) & ((xx % 16) == 8), 220, 20).astype(np.uint8)
     p = api.default_orb_params(50)
+    kg, dg = ctx.orb_extract(board, p)
+    ko, do = oracle.orb_extract(board, _oracle_params(oracle, p), cap=8192)
+    assert len(ko) == 976 and (ko["octave"] == 0).sum() == 936
+    _same_keypoints(kg, dg, ko, do)
     with pytest.raises(api.MslamError) as e:
         ctx.orb_extract(board, p, cap=64)
     assert e.value.status == api.ERR_CAPACITY
