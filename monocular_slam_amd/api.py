@@ -92,6 +92,18 @@ def _p(a, t):
     return a.ctypes.data_as(t)
 
 
+def default_fmat_params() -> FmatParams:
+    p = FmatParams()
+    lib().mslam_fmat_default_params(C.byref(p))
+    return p
+
+
+def default_pnp_params() -> PnpParams:
+    p = PnpParams()
+    lib().mslam_pnp_default_params(C.byref(p))
+    return p
+
+
 def default_orb_params(nfeatures: int = 500) -> OrbParams:
     p = OrbParams()
     lib().mslam_orb_default_params(C.byref(p))
@@ -204,6 +216,71 @@ class Context:
                                               vp(idx_ptr), vp(dist_ptr), C.c_float(ratio), o(m_query_ptr), o(m_train_ptr),
                                               o(m_dist_ptr), o(m_count_ptr))
         self._check(rc, "mslam_match_knn2_batch_dev")
+
+
+def _ctx_methods():
+    def fmat_ransac8(self, x1, x2, samples, params: FmatParams):
+        """R8/R9: eight-point F-matrix RANSAC over an explicit H x 8 sample table."""
+        x1 = np.ascontiguousarray(x1, np.float64); x2 = np.ascontiguousarray(x2, np.float64)
+        samples = np.ascontiguousarray(samples, np.int32)
+        M, H = x1.shape[0], samples.shape[0]
+        F = np.zeros(9); status = np.zeros(M, np.uint8); counts = np.zeros(H, np.int32)
+        best, ninl = C.c_int(-1), C.c_int(0)
+        rc = lib().mslam_fmat_ransac8(self._h, _p(x1, f64p), _p(x2, f64p), M, _p(samples, i32p), H, C.byref(params),
+                                      _p(F, f64p), _p(status, u8p), _p(counts, i32p), C.byref(best), C.byref(ninl))
+        if rc not in (OK, ERR_DEGENERATE):
+            self._check(rc, "mslam_fmat_ransac8")
+        return dict(rc=rc, F=F.reshape(3, 3), status=status, counts=counts, best_h=best.value, n_inliers=ninl.value)
+
+    def pnp_ransac(self, X, x, K, dist, samples, params: PnpParams):
+        """R12: PnP RANSAC (P3P hypotheses over an explicit H x 4 sample table)."""
+        X = np.ascontiguousarray(X, np.float64); x = np.ascontiguousarray(x, np.float64)
+        K = np.ascontiguousarray(K, np.float64); dist = np.ascontiguousarray(dist, np.float64)
+        samples = np.ascontiguousarray(samples, np.int32)
+        P, H = X.shape[0], samples.shape[0]
+        rvec, tvec, Rt = np.zeros(3), np.zeros(3), np.zeros(12)
+        inl = np.zeros(P, np.uint8); counts = np.zeros(H, np.int32)
+        best, ninl = C.c_int(-1), C.c_int(0)
+        rc = lib().mslam_pnp_ransac(self._h, _p(X, f64p), _p(x, f64p), P, _p(K, f64p), _p(dist, f64p), _p(samples, i32p), H,
+                                    C.byref(params), _p(rvec, f64p), _p(tvec, f64p), _p(Rt, f64p), _p(inl, u8p),
+                                    _p(counts, i32p), C.byref(best), C.byref(ninl))
+        if rc not in (OK, ERR_DEGENERATE):
+            self._check(rc, "mslam_pnp_ransac")
+        return dict(rc=rc, rvec=rvec, tvec=tvec, Rt=Rt.reshape(3, 4), inliers=inl, counts=counts, best_h=best.value,
+                    n_inliers=ninl.value)
+
+    def triangulate(self, x1, x2, Rt1, Rt2, K1, K2):
+        """R11: two-view DLT triangulation + cheirality flags."""
+        x1 = np.ascontiguousarray(x1, np.float64); x2 = np.ascontiguousarray(x2, np.float64)
+        n = x1.shape[0]
+        X = np.zeros((n, 3)); front = np.zeros(n, np.uint8); nf = C.c_int(0)
+        a = [np.ascontiguousarray(m, np.float64) for m in (Rt1, Rt2, K1, K2)]
+        self._check(lib().mslam_triangulate(self._h, _p(x1, f64p), _p(x2, f64p), n, _p(a[0], f64p), _p(a[1], f64p),
+                                            _p(a[2], f64p), _p(a[3], f64p), _p(X, f64p), _p(front, u8p), C.byref(nf)),
+                    "mslam_triangulate")
+        return X, front, nf.value
+
+    def fmat_ransac8_batch_dev(self, x1_ptr, x2_ptr, M_ptr, capM, samples_ptr, H, B, params, F_ptr, status_ptr,
+                               counts_ptr, best_ptr, ninl_ptr):
+        self._check(lib().mslam_fmat_ransac8_batch_dev(self._h, vp(x1_ptr), vp(x2_ptr), vp(M_ptr), capM, vp(samples_ptr), H, B,
+                                                       C.byref(params), vp(F_ptr), vp(status_ptr),
+                                                       vp(counts_ptr) if counts_ptr else None, vp(best_ptr), vp(ninl_ptr)),
+                    "mslam_fmat_ransac8_batch_dev")
+
+    def pnp_ransac_batch_dev(self, X_ptr, x_ptr, P_ptr, capP, K_ptr, dist_ptr, samples_ptr, H, B, params, Rt_ptr,
+                             rvec_ptr, tvec_ptr, inl_ptr, counts_ptr, best_ptr, ninl_ptr):
+        def o(p):
+            return vp(p) if p else None
+        self._check(lib().mslam_pnp_ransac_batch_dev(self._h, vp(X_ptr), vp(x_ptr), vp(P_ptr), capP, vp(K_ptr), vp(dist_ptr),
+                                                     vp(samples_ptr), H, B, C.byref(params), vp(Rt_ptr), o(rvec_ptr),
+                                                     o(tvec_ptr), vp(inl_ptr), o(counts_ptr), vp(best_ptr), vp(ninl_ptr)),
+                    "mslam_pnp_ransac_batch_dev")
+
+    for f in (fmat_ransac8, pnp_ransac, triangulate, fmat_ransac8_batch_dev, pnp_ransac_batch_dev):
+        setattr(Context, f.__name__, f)
+
+
+_ctx_methods()
 
 
 class DevBuf:

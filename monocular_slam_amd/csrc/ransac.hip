@@ -1,0 +1,1339 @@
+// ransac.hip -- K8: eight-point fundamental-matrix RANSAC, PnP (P3P) RANSAC, two-view
+// triangulation (gfx950).  All f64, plain IEEE evaluation (built with -ffp-contract=off) so
+// that every inlier decision equals the CPU restatement's.
+//
+// Stands in for computeFundamentalMatrix / computeFundamentalMatrix2 (reference
+// src/CameraPoseEstimator.cpp:545-586, :596-786), solvePnPRansac + Rodrigues (:472-473) and
+// TriangulateMultiplePointsFromTwoView (:136-152).
+//
+// Structure (per batch of independent problems):
+//   *_prepare_k   per-point preprocessing (scaling through float / iterative undistortion)
+//   *_solve_k     ONE HYPOTHESIS PER LANE: minimal solver (8x9 Gauss-Jordan null vector +
+//                 rank-2, or P3P + 4th-point disambiguation) -> model table in HBM
+//   *_score_k     ONE HYPOTHESIS PER WAVEFRONT-ITERATION: a workgroup owns HT hypotheses
+//                 (models staged in LDS), its lanes stride over the points (each point is
+//                 loaded once and reused HT times from registers), inlier votes are taken
+//                 with __ballot + popcount and summed per hypothesis in LDS
+//   select_k      argmax (max count, lowest index) with OpenCV's adaptive iteration bound
+//                 emulated over the ordered counts
+//   *_finalize_k  one workgroup per problem: inlier mask of the winner, refit (block
+//                 reductions, fixed tree order => run-to-run deterministic), outputs
+// No MFMA: the work is small fixed-size solves and a scored reduction, not a contraction.
+#include "common.h"
+#include <cfloat>
+#include <cmath>
+
+namespace {
+
+constexpr int HT = 16;             // hypotheses per scoring workgroup
+constexpr int SCORE_THREADS = 256;
+
+// ------------------------------------------------------------------ small linear algebra
+__device__ __forceinline__ double det3(const double* A)
+{
+    return A[0] * (A[4] * A[8] - A[5] * A[7]) - A[1] * (A[3] * A[8] - A[5] * A[6]) + A[2] * (A[3] * A[7] - A[4] * A[6]);
+}
+
+__device__ __forceinline__ void adj3s(const double* A, double* J)
+{
+    J[0] = A[4] * A[8] - A[5] * A[7]; J[1] = A[2] * A[7] - A[1] * A[8]; J[2] = A[1] * A[5] - A[2] * A[4];
+    J[3] = A[5] * A[6] - A[3] * A[8]; J[4] = A[0] * A[8] - A[2] * A[6]; J[5] = A[2] * A[3] - A[0] * A[5];
+    J[6] = A[3] * A[7] - A[4] * A[6]; J[7] = A[1] * A[6] - A[0] * A[7]; J[8] = A[0] * A[4] - A[1] * A[3];
+}
+
+// One Jacobi rotation on the pair (p,q) of a symmetric 3x3 held in scalars.  (x,y) are the two
+// off-diagonal entries that couple p and q to the third index; vXp/vXq are eigenvector entries.
+#define JAC3_ROT(apq, dp, dq, zp, zq, x, y, v0p, v0q, v1p, v1q, v2p, v2q)                               \
+    {                                                                                                     \
+        double g = 100.0 * fabs(apq);                                                                     \
+        if (sweep > 4 && fabs(dp) + g == fabs(dp) && fabs(dq) + g == fabs(dq)) { apq = 0.0; }             \
+        else if (fabs(apq) > tresh) {                                                                     \
+            double h = dq - dp, t;                                                                        \
+            if (fabs(h) + g == fabs(h)) t = apq / h;                                                      \
+            else {                                                                                        \
+                double theta = 0.5 * h / apq;                                                             \
+                t = 1.0 / (fabs(theta) + sqrt(1.0 + theta * theta));                                      \
+                if (theta < 0.0) t = -t;                                                                  \
+            }                                                                                             \
+            double c = 1.0 / sqrt(1.0 + t * t), s = t * c, tau = s / (1.0 + c);                           \
+            h = t * apq;                                                                                  \
+            zp -= h; zq += h; dp -= h; dq += h; apq = 0.0;                                                \
+            { double X_ = x, Y_ = y; x = X_ - s * (Y_ + X_ * tau); y = Y_ + s * (X_ - Y_ * tau); }        \
+            { double X_ = v0p, Y_ = v0q; v0p = X_ - s * (Y_ + X_ * tau); v0q = Y_ + s * (X_ - Y_ * tau); } \
+            { double X_ = v1p, Y_ = v1q; v1p = X_ - s * (Y_ + X_ * tau); v1q = Y_ + s * (X_ - Y_ * tau); } \
+            { double X_ = v2p, Y_ = v2q; v2p = X_ - s * (Y_ + X_ * tau); v2q = Y_ + s * (X_ - Y_ * tau); } \
+        }                                                                                                 \
+    }
+
+// cyclic Jacobi for symmetric 3x3 (same sweep/threshold rules as the generic n x n routine);
+// eigenvalues ascending in w, eigenvectors in the columns of V (row-major)
+__device__ void jacobi3(const double* A, double* w, double* V)
+{
+    double a01 = A[1], a02 = A[2], a12 = A[5];
+    double d0 = A[0], d1 = A[4], d2 = A[8];
+    double b0 = d0, b1 = d1, b2 = d2, z0 = 0.0, z1 = 0.0, z2 = 0.0;
+    double v00 = 1.0, v01 = 0.0, v02 = 0.0, v10 = 0.0, v11 = 1.0, v12 = 0.0, v20 = 0.0, v21 = 0.0, v22 = 1.0;
+    for (int sweep = 1; sweep <= 60; sweep++) {
+        double sm = fabs(a01) + fabs(a02) + fabs(a12);
+        if (sm == 0.0) break;
+        double tresh = sweep < 4 ? 0.2 * sm / 9 : 0.0;
+        JAC3_ROT(a01, d0, d1, z0, z1, a02, a12, v00, v01, v10, v11, v20, v21)
+        JAC3_ROT(a02, d0, d2, z0, z2, a01, a12, v00, v02, v10, v12, v20, v22)
+        JAC3_ROT(a12, d1, d2, z1, z2, a01, a02, v01, v02, v11, v12, v21, v22)
+        b0 += z0; d0 = b0; z0 = 0.0;
+        b1 += z1; d1 = b1; z1 = 0.0;
+        b2 += z2; d2 = b2; z2 = 0.0;
+    }
+    // stable ascending order of (d0,d1,d2)
+    int o0 = 0, o1 = 1, o2 = 2;
+    double e0 = d0, e1 = d1, e2 = d2;
+    // selection: smallest first (first index wins ties)
+    if (e1 < e0) { double t = e0; e0 = e1; e1 = t; int ti = o0; o0 = o1; o1 = ti; }
+    if (e2 < e0) { double t = e0; e0 = e2; e2 = e1; e1 = t; int ti = o0; o0 = o2; o2 = o1; o1 = ti; }
+    else if (e2 < e1) { double t = e1; e1 = e2; e2 = t; int ti = o1; o1 = o2; o2 = ti; }
+    w[0] = e0; w[1] = e1; w[2] = e2;
+    const double vr[3][3] = { { v00, v01, v02 }, { v10, v11, v12 }, { v20, v21, v22 } };
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        V[r * 3 + 0] = o0 == 0 ? vr[r][0] : (o0 == 1 ? vr[r][1] : vr[r][2]);
+        V[r * 3 + 1] = o1 == 0 ? vr[r][0] : (o1 == 1 ? vr[r][1] : vr[r][2]);
+        V[r * 3 + 2] = o2 == 0 ? vr[r][0] : (o2 == 1 ? vr[r][1] : vr[r][2]);
+    }
+}
+
+// generic cyclic Jacobi on an n x n symmetric matrix held in memory (LDS or scratch), n <= 9.
+// Single-lane, used only by the once-per-problem refits.
+__device__ void jacobi_mem(double* a, int n, double* d, double* v)
+{
+    double bb[9], z[9];
+    for (int i = 0; i < n; i++) {
+        for (int j = 0; j < n; j++) v[i * n + j] = (i == j) ? 1.0 : 0.0;
+        d[i] = bb[i] = a[i * n + i];
+        z[i] = 0.0;
+    }
+    for (int sweep = 1; sweep <= 60; sweep++) {
+        double sm = 0.0;
+        for (int p = 0; p < n - 1; p++)
+            for (int q = p + 1; q < n; q++) sm += fabs(a[p * n + q]);
+        if (sm == 0.0) break;
+        double tresh = sweep < 4 ? 0.2 * sm / (n * n) : 0.0;
+        for (int p = 0; p < n - 1; p++)
+            for (int q = p + 1; q < n; q++) {
+                double apq = a[p * n + q];
+                double g = 100.0 * fabs(apq);
+                if (sweep > 4 && fabs(d[p]) + g == fabs(d[p]) && fabs(d[q]) + g == fabs(d[q])) a[p * n + q] = 0.0;
+                else if (fabs(apq) > tresh) {
+                    double h = d[q] - d[p], t;
+                    if (fabs(h) + g == fabs(h)) t = apq / h;
+                    else {
+                        double theta = 0.5 * h / apq;
+                        t = 1.0 / (fabs(theta) + sqrt(1.0 + theta * theta));
+                        if (theta < 0.0) t = -t;
+                    }
+                    double c = 1.0 / sqrt(1.0 + t * t), s = t * c, tau = s / (1.0 + c);
+                    h = t * apq;
+                    z[p] -= h; z[q] += h; d[p] -= h; d[q] += h;
+                    a[p * n + q] = 0.0;
+                    for (int j = 0; j < p; j++) { double x = a[j * n + p], y = a[j * n + q]; a[j * n + p] = x - s * (y + x * tau); a[j * n + q] = y + s * (x - y * tau); }
+                    for (int j = p + 1; j < q; j++) { double x = a[p * n + j], y = a[j * n + q]; a[p * n + j] = x - s * (y + x * tau); a[j * n + q] = y + s * (x - y * tau); }
+                    for (int j = q + 1; j < n; j++) { double x = a[p * n + j], y = a[q * n + j]; a[p * n + j] = x - s * (y + x * tau); a[q * n + j] = y + s * (x - y * tau); }
+                    for (int j = 0; j < n; j++) { double x = v[j * n + p], y = v[j * n + q]; v[j * n + p] = x - s * (y + x * tau); v[j * n + q] = y + s * (x - y * tau); }
+                }
+            }
+        for (int i = 0; i < n; i++) { bb[i] += z[i]; d[i] = bb[i]; z[i] = 0.0; }
+    }
+}
+
+// index of the smallest eigenvalue, first index on ties (== column 0 after the stable ascending sort)
+__device__ __forceinline__ int argmin_first(const double* d, int n)
+{
+    int k = 0;
+    for (int i = 1; i < n; i++) if (d[i] < d[k]) k = i;
+    return k;
+}
+
+// F <- F - (F v3) v3^T with v3 the right singular vector of the smallest singular value
+__device__ void rank2(double* F)
+{
+    double FtF[9], w[3], V[9];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            double acc = 0;
+#pragma unroll
+            for (int k = 0; k < 3; k++) acc += F[k * 3 + i] * F[k * 3 + j];
+            FtF[i * 3 + j] = acc;
+        }
+    jacobi3(FtF, w, V);
+    const double v3[3] = { V[0], V[3], V[6] };
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        double fv = F[r * 3] * v3[0] + F[r * 3 + 1] * v3[1] + F[r * 3 + 2] * v3[2];
+#pragma unroll
+        for (int c = 0; c < 3; c++) F[r * 3 + c] = F[r * 3 + c] - fv * v3[c];
+    }
+}
+
+// Null vector of an 8x9 system: Gauss-Jordan with complete pivoting, everything in registers
+// (fully unrolled; dynamic pivot positions are handled with selects, never with indexed arrays).
+__device__ void null_8x9(double (&A)[8][9], double* f)
+{
+    unsigned used_r = 0, used_c = 0;
+    int prow[8], pcol[8];
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        double best = -1.0;
+        int br = 0, bc = 0;
+#pragma unroll
+        for (int r = 0; r < 8; r++)
+#pragma unroll
+            for (int c = 0; c < 9; c++) {
+                double v = fabs(A[r][c]);
+                bool take = !((used_r >> r) & 1u) && !((used_c >> c) & 1u) && v > best;
+                best = take ? v : best; br = take ? r : br; bc = take ? c : bc;
+            }
+        used_r |= 1u << br; used_c |= 1u << bc; prow[k] = br; pcol[k] = bc;
+        double piv[9];
+#pragma unroll
+        for (int c = 0; c < 9; c++) {
+            double v = A[0][c];
+#pragma unroll
+            for (int r = 1; r < 8; r++) v = (r == br) ? A[r][c] : v;
+            piv[c] = v;
+        }
+        double pv = piv[0];
+#pragma unroll
+        for (int c = 1; c < 9; c++) pv = (c == bc) ? piv[c] : pv;
+        if (pv == 0.0) ok = false;
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            double arc = A[r][0];
+#pragma unroll
+            for (int c = 1; c < 9; c++) arc = (c == bc) ? A[r][c] : arc;
+            double m = arc / pv;
+            bool upd = (r != br);
+#pragma unroll
+            for (int c = 0; c < 9; c++) {
+                double nv = (c == bc) ? 0.0 : A[r][c] - m * piv[c];
+                A[r][c] = upd ? nv : A[r][c];
+            }
+        }
+    }
+    int cf = 0;
+#pragma unroll
+    for (int c = 0; c < 9; c++) cf = ((used_c >> c) & 1u) ? cf : c;
+    double fv[9];
+#pragma unroll
+    for (int c = 0; c < 9; c++) fv[c] = (c == cf) ? 1.0 : 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        double num = 0.0, den = 1.0;
+#pragma unroll
+        for (int r = 0; r < 8; r++)
+#pragma unroll
+            for (int c = 0; c < 9; c++) {
+                bool isr = (r == prow[k]);
+                num = (isr && c == cf) ? A[r][c] : num;
+                den = (isr && c == pcol[k]) ? A[r][c] : den;
+            }
+        double val = -num / den;
+#pragma unroll
+        for (int c = 0; c < 9; c++) fv[c] = (c == pcol[k]) ? val : fv[c];
+    }
+    double nn = 0.0;
+#pragma unroll
+    for (int c = 0; c < 9; c++) nn += fv[c] * fv[c];
+    nn = sqrt(nn);
+#pragma unroll
+    for (int c = 0; c < 9; c++) f[c] = ok ? fv[c] / nn : 0.0;
+}
+
+// ------------------------------------------------------------------ fundamental matrix
+struct FmatArgs {
+    const double* x1; const double* x2; const int32_t* M; int capM;
+    const int32_t* samples; int H; int B;
+    int metric; double thr; double confidence; int refit;
+    double* pts;      // [B][capM][4]: (u1,v1,u2,v2) in the scoring representation
+    double* maxt;     // [B]
+    double* models;   // [B][H][9] scoring F (scaled or pixel units by metric)
+    double* models_s; // [B][H][9] F for the max-scaled coordinates (refit 0 de-normalises it)
+    int32_t* counts;  // [B][H]
+    int32_t* best;    // [B]
+    double* F; uint8_t* status; int32_t* n_inliers;
+};
+
+__global__ __launch_bounds__(256)
+void fmat_prepare_k(FmatArgs a)
+{
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int M = a.M[b];
+    const double* x1 = a.x1 + (size_t)b * a.capM * 2;
+    const double* x2 = a.x2 + (size_t)b * a.capM * 2;
+    __shared__ double s_max[256];
+    double m = 0.0;
+    for (int i = tid; i < M; i += 256) { // max is order independent (:609-613)
+        m = fmax(m, fmax(x1[2 * i], x2[2 * i]));
+        m = fmax(m, fmax(x1[2 * i + 1], x2[2 * i + 1]));
+    }
+    s_max[tid] = m;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (tid < o) s_max[tid] = fmax(s_max[tid], s_max[tid + o]); __syncthreads(); }
+    const double maxt = s_max[0];
+    if (tid == 0) a.maxt[b] = maxt;
+    double* pts = a.pts + (size_t)b * a.capM * 4;
+    for (int i = tid; i < M; i += 256) {
+        double u1 = x1[2 * i], v1 = x1[2 * i + 1], u2 = x2[2 * i], v2 = x2[2 * i + 1];
+        if (a.metric == 0) { // through float, as p_match (:31-34, :615-633)
+            u1 = (double)(float)(u1 / maxt); v1 = (double)(float)(v1 / maxt);
+            u2 = (double)(float)(u2 / maxt); v2 = (double)(float)(v2 / maxt);
+        }
+        pts[4 * i] = u1; pts[4 * i + 1] = v1; pts[4 * i + 2] = u2; pts[4 * i + 3] = v2;
+    }
+}
+
+__global__ __launch_bounds__(64)
+void fmat_solve_k(FmatArgs a)
+{
+    const int b = blockIdx.y;
+    const int h = blockIdx.x * 64 + threadIdx.x;
+    if (h >= a.H) return;
+    const int M = a.M[b];
+    const double maxt = a.maxt[b];
+    const double* x1 = a.x1 + (size_t)b * a.capM * 2;
+    const double* x2 = a.x2 + (size_t)b * a.capM * 2;
+    const int32_t* s = a.samples + ((size_t)b * a.H + h) * 8;
+    double A[8][9];
+    bool valid = M >= 8 && maxt > 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        int i = s[k];
+        if (i < 0 || i >= M) { valid = false; i = 0; }
+        float u1 = (float)(x1[2 * i] / maxt), v1 = (float)(x1[2 * i + 1] / maxt);
+        float u2 = (float)(x2[2 * i] / maxt), v2 = (float)(x2[2 * i + 1] / maxt);
+        A[k][0] = (double)(u2 * u1); A[k][1] = (double)(u2 * v1); A[k][2] = (double)u2;
+        A[k][3] = (double)(v2 * u1); A[k][4] = (double)(v2 * v1); A[k][5] = (double)v2;
+        A[k][6] = (double)u1; A[k][7] = (double)v1; A[k][8] = 1.0;
+    }
+    double F[9];
+    null_8x9(A, F);
+    rank2(F);
+    double* ms = a.models_s + ((size_t)b * a.H + h) * 9;
+    double* mo = a.models + ((size_t)b * a.H + h) * 9;
+    const double t[3] = { 1.0 / maxt, 1.0 / maxt, 1.0 };
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            double v = valid ? F[i * 3 + j] : 0.0;
+            ms[i * 3 + j] = v;
+            mo[i * 3 + j] = a.metric == 0 ? v : t[i] * v * t[j]; // times_F^T F times_F (:666-669)
+        }
+}
+
+__device__ __forceinline__ bool fmat_inlier(const double* F, double u1, double v1, double u2, double v2, int metric, double thr)
+{
+    if (metric == 0) { // getInlier (:715-763)
+        double Fx1u = F[0] * u1 + F[1] * v1 + F[2];
+        double Fx1v = F[3] * u1 + F[4] * v1 + F[5];
+        double Fx1w = F[6] * u1 + F[7] * v1 + F[8];
+        double Ftx2u = F[0] * u2 + F[3] * v2 + F[6];
+        double Ftx2v = F[1] * u2 + F[4] * v2 + F[7];
+        double x2tFx1 = u2 * Fx1u + v2 * Fx1v + Fx1w;
+        double d = x2tFx1 * x2tFx1 / (Fx1u * Fx1u + Fx1v * Fx1v + Ftx2u * Ftx2u + Ftx2v * Ftx2v);
+        return fabs(d) < thr;
+    }
+    double aa = F[0] * u1 + F[1] * v1 + F[2];
+    double bb = F[3] * u1 + F[4] * v1 + F[5];
+    double cc = F[6] * u1 + F[7] * v1 + F[8];
+    double s2 = 1. / (aa * aa + bb * bb);
+    double d2 = u2 * aa + v2 * bb + cc;
+    aa = F[0] * u2 + F[3] * v2 + F[6];
+    bb = F[1] * u2 + F[4] * v2 + F[7];
+    cc = F[2] * u2 + F[5] * v2 + F[8];
+    double s1 = 1. / (aa * aa + bb * bb);
+    double d1 = u1 * aa + v1 * bb + cc;
+    double e1 = d1 * d1 * s1, e2 = d2 * d2 * s2;
+    return (double)(float)(e1 > e2 ? e1 : e2) <= thr; // err is stored as float by OpenCV
+}
+
+__global__ __launch_bounds__(SCORE_THREADS)
+void fmat_score_k(FmatArgs a)
+{
+    const int b = blockIdx.y, h0 = blockIdx.x * HT, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int M = a.M[b];
+    __shared__ double s_F[HT][9];
+    __shared__ int s_cnt[HT];
+    if (tid < HT * 9) {
+        int hh = tid / 9, e = tid % 9;
+        s_F[hh][e] = (h0 + hh < a.H) ? a.models[((size_t)b * a.H + h0 + hh) * 9 + e] : 0.0;
+    }
+    if (tid < HT) s_cnt[tid] = 0;
+    __syncthreads();
+    int cnt[HT];
+#pragma unroll
+    for (int k = 0; k < HT; k++) cnt[k] = 0;
+    const double4* pts = reinterpret_cast<const double4*>(a.pts + (size_t)b * a.capM * 4);
+    for (int i0 = 0; i0 < M; i0 += SCORE_THREADS) {
+        const int i = i0 + tid;
+        const bool live = i < M;
+        double4 p = live ? pts[i] : make_double4(0, 0, 0, 0);
+#pragma unroll
+        for (int k = 0; k < HT; k++) {
+            bool in = live && fmat_inlier(s_F[k], p.x, p.y, p.z, p.w, a.metric, a.thr);
+            cnt[k] += __popcll(__ballot(in)); // wave-uniform
+        }
+    }
+    if (lane == 0)
+#pragma unroll
+        for (int k = 0; k < HT; k++) atomicAdd(&s_cnt[k], cnt[k]);
+    __syncthreads();
+    if (tid < HT && h0 + tid < a.H) a.counts[(size_t)b * a.H + h0 + tid] = s_cnt[tid];
+    (void)wave;
+}
+
+// cvRANSACUpdateNumIters
+__device__ int ransac_update_iters(double p, double ep, int model_points, int max_iters)
+{
+    p = p > 0. ? p : 0.; p = p < 1. ? p : 1.;
+    ep = ep > 0. ? ep : 0.; ep = ep < 1. ? ep : 1.;
+    double num = 1. - p > DBL_MIN ? 1. - p : DBL_MIN;
+    double denom = 1. - pow(1. - ep, (double)model_points);
+    if (denom < DBL_MIN) return 0;
+    num = log(num);
+    denom = log(denom);
+    return denom >= 0 || -num >= max_iters * (-denom) ? max_iters : (int)rint(num / denom);
+}
+
+// one wavefront per problem: winner over the ordered counts (max count, lowest index) inside
+// the adaptive iteration bound.  Chunks of 64 counts are skipped unless one beats the best.
+__global__ __launch_bounds__(64)
+void ransac_select_k(const int32_t* __restrict__ counts, const int32_t* __restrict__ npts, int H, int sample_size,
+                     double confidence, int32_t* __restrict__ best_out, int32_t* __restrict__ best_cnt_out)
+{
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int32_t* c = counts + (size_t)b * H;
+    const int n_points = npts[b];
+    const bool adaptive = confidence > 0. && confidence < 1.;
+    int niters = H, best = -1, maxgood = 0;
+    for (int i0 = 0; i0 < niters; i0 += 64) {
+        const int i = i0 + lane;
+        const int v = i < H ? c[i] : -1;
+        int floor_ = maxgood > sample_size - 1 ? maxgood : sample_size - 1;
+        unsigned long long bal = __ballot(i < niters && v > floor_);
+        while (bal) { // record breakers in index order
+            const int j = __ffsll((long long)bal) - 1;
+            bal &= bal - 1;
+            const int it = i0 + j;
+            if (it >= niters) break;
+            const int good = __shfl(v, j);
+            floor_ = maxgood > sample_size - 1 ? maxgood : sample_size - 1;
+            if (good > floor_) {
+                best = it; maxgood = good;
+                if (adaptive && n_points > 0)
+                    niters = ransac_update_iters(confidence, (double)(n_points - good) / n_points, sample_size, niters);
+            }
+        }
+    }
+    if (lane == 0) { best_out[b] = best; if (best_cnt_out) best_cnt_out[b] = maxgood; }
+}
+
+// block-wide sum of NV doubles per thread, fixed tree order (deterministic)
+template <int NV>
+__device__ void block_reduce(double (&v)[NV], double* s_red /*[NV][256]*/, int tid)
+{
+#pragma unroll
+    for (int k = 0; k < NV; k++) s_red[k * 256 + tid] = v[k];
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o)
+#pragma unroll
+            for (int k = 0; k < NV; k++) s_red[k * 256 + tid] += s_red[k * 256 + tid + o];
+        __syncthreads();
+    }
+#pragma unroll
+    for (int k = 0; k < NV; k++) v[k] = s_red[k * 256];
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256)
+void fmat_finalize_k(FmatArgs a)
+{
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int M = a.M[b];
+    const int best = a.best[b];
+    uint8_t* status = a.status + (size_t)b * a.capM;
+    double* Fout = a.F + (size_t)b * 9;
+    __shared__ double s_red[9 * 256];
+    __shared__ double s_A[81], s_V[81], s_d[9], s_F[9];
+    __shared__ int s_n;
+    if (best < 0) {
+        for (int i = tid; i < M; i += 256) status[i] = 0;
+        if (tid < 9) Fout[tid] = 0.0;
+        if (tid == 0) a.n_inliers[b] = 0;
+        return;
+    }
+    if (tid < 9) s_F[tid] = a.models[((size_t)b * a.H + best) * 9 + tid];
+    if (tid == 0) s_n = 0;
+    __syncthreads();
+    const double4* pts = reinterpret_cast<const double4*>(a.pts + (size_t)b * a.capM * 4);
+    const double* x1 = a.x1 + (size_t)b * a.capM * 2;
+    const double* x2 = a.x2 + (size_t)b * a.capM * 2;
+    const double maxt = a.maxt[b];
+    int my = 0;
+    for (int i = tid; i < M; i += 256) {
+        double4 p = pts[i];
+        bool in = fmat_inlier(s_F, p.x, p.y, p.z, p.w, a.metric, a.thr);
+        status[i] = (uint8_t)in;
+        my += in;
+    }
+    atomicAdd(&s_n, my);
+    __syncthreads();
+    const int n = s_n;
+    if (tid == 0) a.n_inliers[b] = n;
+    if (a.refit == 0 || n < 8) {
+        if (tid < 9) {
+            const double t[3] = { 1.0 / maxt, 1.0 / maxt, 1.0 };
+            Fout[tid] = t[tid / 3] * a.models_s[((size_t)b * a.H + best) * 9 + tid] * t[tid % 3];
+        }
+        return;
+    }
+    // ---- refit on the inliers: accumulate A^T A (45 unique sums; upper triangle), Jacobi on one lane
+    double c0x = 0, c0y = 0, c1x = 0, c1y = 0, s0 = 1, s1 = 1;
+    if (a.refit == 2) { // Hartley normalisation (run8Point)
+        double acc[4] = { 0, 0, 0, 0 };
+        for (int i = tid; i < M; i += 256)
+            if (status[i]) { acc[0] += x1[2 * i]; acc[1] += x1[2 * i + 1]; acc[2] += x2[2 * i]; acc[3] += x2[2 * i + 1]; }
+        block_reduce<4>(acc, s_red, tid);
+        const double t = 1. / n;
+        c0x = acc[0] * t; c0y = acc[1] * t; c1x = acc[2] * t; c1y = acc[3] * t;
+        double sc[2] = { 0, 0 };
+        for (int i = tid; i < M; i += 256)
+            if (status[i]) {
+                double dx = x1[2 * i] - c0x, dy = x1[2 * i + 1] - c0y;
+                sc[0] += sqrt(dx * dx + dy * dy);
+                dx = x2[2 * i] - c1x; dy = x2[2 * i + 1] - c1y;
+                sc[1] += sqrt(dx * dx + dy * dy);
+            }
+        block_reduce<2>(sc, s_red, tid);
+        s0 = sc[0] * t; s1 = sc[1] * t;
+        if (s0 < (double)FLT_EPSILON || s1 < (double)FLT_EPSILON) { if (tid < 9) Fout[tid] = 0.0; return; }
+        s0 = sqrt(2.) / s0; s1 = sqrt(2.) / s1;
+    }
+    for (int r0 = 0; r0 < 9; r0++) { // 9 passes, one row of the upper triangle each (keeps LDS small)
+        double acc[9];
+#pragma unroll
+        for (int k = 0; k < 9; k++) acc[k] = 0.0;
+        for (int i = tid; i < M; i += 256) {
+            if (!status[i]) continue;
+            double r[9];
+            if (a.refit == 2) {
+                double X0 = (x1[2 * i] - c0x) * s0, Y0 = (x1[2 * i + 1] - c0y) * s0;
+                double X1 = (x2[2 * i] - c1x) * s1, Y1 = (x2[2 * i + 1] - c1y) * s1;
+                r[0] = X1 * X0; r[1] = X1 * Y0; r[2] = X1; r[3] = Y1 * X0; r[4] = Y1 * Y0; r[5] = Y1; r[6] = X0; r[7] = Y0; r[8] = 1;
+            } else {
+                float u1 = (float)(x1[2 * i] / maxt), v1 = (float)(x1[2 * i + 1] / maxt);
+                float u2 = (float)(x2[2 * i] / maxt), v2 = (float)(x2[2 * i + 1] / maxt);
+                r[0] = (double)(u2 * u1); r[1] = (double)(u2 * v1); r[2] = (double)u2; r[3] = (double)(v2 * u1);
+                r[4] = (double)(v2 * v1); r[5] = (double)v2; r[6] = (double)u1; r[7] = (double)v1; r[8] = 1.0;
+            }
+            double rr = r[0];
+#pragma unroll
+            for (int k = 1; k < 9; k++) rr = (k == r0) ? r[k] : rr;
+#pragma unroll
+            for (int k = 0; k < 9; k++) acc[k] += rr * r[k];
+        }
+        block_reduce<9>(acc, s_red, tid);
+        if (tid == 0)
+            for (int k = 0; k < 9; k++) s_A[r0 * 9 + k] = acc[k];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        for (int i = 0; i < 9; i++) for (int j = 0; j < i; j++) s_A[i * 9 + j] = s_A[j * 9 + i]; // symmetric copy of the upper triangle
+        jacobi_mem(s_A, 9, s_d, s_V);
+        const int k0 = argmin_first(s_d, 9);
+        double F0[9];
+        for (int e = 0; e < 9; e++) F0[e] = s_V[e * 9 + k0];
+        bool okf = true;
+        if (a.refit == 2) { // at most one numerically zero eigenvalue
+            int nz = 0;
+            for (int e = 0; e < 9; e++) nz += fabs(s_d[e]) < DBL_EPSILON;
+            okf = nz <= 1;
+        }
+        rank2(F0);
+        double R[9];
+        if (a.refit == 2) {
+            const double T0[9] = { s0, 0, -s0 * c0x, 0, s0, -s0 * c0y, 0, 0, 1 };
+            const double T1[9] = { s1, 0, -s1 * c1x, 0, s1, -s1 * c1y, 0, 0, 1 };
+            double tmp[9];
+            for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { double acc = 0; for (int k = 0; k < 3; k++) acc += T1[k * 3 + i] * F0[k * 3 + j]; tmp[i * 3 + j] = acc; }
+            for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { double acc = 0; for (int k = 0; k < 3; k++) acc += tmp[i * 3 + k] * T0[k * 3 + j]; R[i * 3 + j] = acc; }
+            if (fabs(R[8]) > (double)FLT_EPSILON) { double sc = 1. / R[8]; for (int e = 0; e < 9; e++) R[e] *= sc; }
+        } else {
+            const double t[3] = { 1.0 / maxt, 1.0 / maxt, 1.0 };
+            for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) R[i * 3 + j] = t[i] * F0[i * 3 + j] * t[j];
+        }
+        for (int e = 0; e < 9; e++) Fout[e] = okf ? R[e] : 0.0;
+    }
+}
+
+// ------------------------------------------------------------------ PnP
+struct PnpArgs {
+    const double* X; const double* x; const int32_t* P; int capP;
+    const double* K; const double* dist; const int32_t* samples; int H; int B;
+    double thr, thr2cut, confidence; int refine_iters, min_inliers;
+    double* xn;       // [B][capP][2] undistorted normalised image points
+    double* models;   // [B][H][12] hypothesis poses (row-major 3x4); invalid = all zero
+    int32_t* counts;  // [B][H]
+    int32_t* best; int32_t* best_cnt;
+    double* Rt; double* rvec; double* tvec; uint8_t* inliers; int32_t* n_inliers; int32_t* status;
+};
+
+__device__ __forceinline__ void project_pt(const double* Rt, double fx, double fy, double cx, double cy, const double* k,
+                                           bool has_dist, double X, double Y, double Z, double& u, double& v)
+{
+    // cvProjectPoints2
+    double x = Rt[0] * X + Rt[1] * Y + Rt[2] * Z + Rt[3];
+    double y = Rt[4] * X + Rt[5] * Y + Rt[6] * Z + Rt[7];
+    double z = Rt[8] * X + Rt[9] * Y + Rt[10] * Z + Rt[11];
+    z = z ? 1. / z : 1;
+    x *= z; y *= z;
+    double xd = x, yd = y;
+    if (has_dist) {
+        double r2 = x * x + y * y, r4 = r2 * r2, r6 = r4 * r2;
+        double a1 = 2 * x * y, a2 = r2 + 2 * x * x, a3 = r2 + 2 * y * y;
+        double cdist = 1 + k[0] * r2 + k[1] * r4 + k[4] * r6;
+        double icdist2 = 1. / (1 + k[5] * r2 + k[6] * r4 + k[7] * r6);
+        xd = x * cdist * icdist2 + k[2] * a1 + k[3] * a2;
+        yd = y * cdist * icdist2 + k[2] * a3 + k[3] * a1;
+    }
+    u = xd * fx + cx;
+    v = yd * fy + cy;
+}
+
+__global__ __launch_bounds__(256)
+void pnp_prepare_k(PnpArgs a)
+{
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.P[b]) return;
+    const double* K = a.K + b * 9;
+    const double* k = a.dist + b * 8;
+    const double* x = a.x + ((size_t)b * a.capP + i) * 2;
+    const double fx = K[0], fy = K[4], cx = K[2], cy = K[5];
+    const double x0 = (x[0] - cx) / fx, y0 = (x[1] - cy) / fy;
+    double xx = x0, yy = y0;
+    for (int it = 0; it < 10; it++) { // cvUndistortPoints' fixed-point iteration
+        double r2 = xx * xx + yy * yy;
+        double icdist = (1 + ((k[7] * r2 + k[6]) * r2 + k[5]) * r2) / (1 + ((k[4] * r2 + k[1]) * r2 + k[0]) * r2);
+        double dX = 2 * k[2] * xx * yy + k[3] * (r2 + 2 * xx * xx);
+        double dY = k[2] * (r2 + 2 * yy * yy) + 2 * k[3] * xx * yy;
+        xx = (x0 - dX) * icdist;
+        yy = (y0 - dY) * icdist;
+    }
+    double* o = a.xn + ((size_t)b * a.capP + i) * 2;
+    o[0] = xx; o[1] = yy;
+}
+
+// real root of x^3 + a x^2 + b x + c: monotone Newton from beyond the extreme root
+__device__ double cubic_root(double a, double b, double c)
+{
+    double xi = -a / 3.0;
+    double pi = ((xi + a) * xi + b) * xi + c;
+    if (pi == 0.0) return xi;
+    double m = fabs(a) > fabs(b) ? fabs(a) : fabs(b);
+    m = m > fabs(c) ? m : fabs(c);
+    double x = pi > 0.0 ? -(1.0 + m) : (1.0 + m);
+    for (int it = 0; it < 100; it++) {
+        double p = ((x + a) * x + b) * x + c;
+        double dp = (3.0 * x + 2.0 * a) * x + b;
+        if (dp == 0.0) break;
+        double xn = x - p / dp;
+        double dx = fabs(xn - x);
+        x = xn;
+        if (dx <= 1e-15 * fabs(xn) + 1e-300) break;
+    }
+    return x;
+}
+
+__device__ __forceinline__ double quad_form(const double* D, const double* p, const double* q)
+{
+    double Dq0 = D[0] * q[0] + D[1] * q[1] + D[2] * q[2];
+    double Dq1 = D[3] * q[0] + D[4] * q[1] + D[5] * q[2];
+    double Dq2 = D[6] * q[0] + D[7] * q[1] + D[8] * q[2];
+    return p[0] * Dq0 + p[1] * Dq1 + p[2] * Dq2;
+}
+
+__device__ __forceinline__ double sel3(const double* v, int i) { return i == 0 ? v[0] : (i == 1 ? v[1] : v[2]); }
+
+// P3P (see oracle/pnp.c for the derivation): up to 4 poses
+__device__ int p3p(const double* f, const double* X, double (*Rout)[9], double (*tout)[3])
+{
+    const double* f0 = f; const double* f1 = f + 3; const double* f2 = f + 6;
+    double b[3], a[3];
+    b[0] = f0[0] * f1[0] + f0[1] * f1[1] + f0[2] * f1[2];
+    b[1] = f0[0] * f2[0] + f0[1] * f2[1] + f0[2] * f2[2];
+    b[2] = f1[0] * f2[0] + f1[1] * f2[1] + f1[2] * f2[2];
+    double d01[3], d02[3], d12[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) { d01[k] = X[k] - X[3 + k]; d02[k] = X[k] - X[6 + k]; d12[k] = X[3 + k] - X[6 + k]; }
+    a[0] = d01[0] * d01[0] + d01[1] * d01[1] + d01[2] * d01[2];
+    a[1] = d02[0] * d02[0] + d02[1] * d02[1] + d02[2] * d02[2];
+    a[2] = d12[0] * d12[0] + d12[1] * d12[1] + d12[2] * d12[2];
+    if (!(a[0] > 0 && a[1] > 0 && a[2] > 0)) return 0;
+    const double D1[9] = { a[2], -a[2] * b[0], 0, -a[2] * b[0], a[2] - a[0], a[0] * b[2], 0, a[0] * b[2], -a[0] };
+    const double D2[9] = { a[2], 0, -a[2] * b[1], 0, -a[1], a[1] * b[2], -a[2] * b[1], a[1] * b[2], a[2] - a[1] };
+    double J1[9], J2[9];
+    adj3s(D1, J1); adj3s(D2, J2);
+    double c0 = det3(D1), c3 = det3(D2), c1 = 0, c2 = 0;
+#pragma unroll
+    for (int k = 0; k < 9; k++) { c1 += J1[k] * D2[k]; c2 += D1[k] * J2[k]; }
+    double cs = fabs(c0) + fabs(c1) + fabs(c2) + fabs(c3);
+    if (!(fabs(c3) > 1e-12 * cs)) return 0;
+    const double ca = c2 / c3, cb = c1 / c3, cc = c0 / c3;
+    double roots[3];
+    int nroots = 1;
+    roots[0] = cubic_root(ca, cb, cc);
+    {
+        double r = roots[0], p = ca + r, q = cb + p * r;
+        double disc = p * p - 4.0 * q;
+        if (disc >= 0.0) {
+            double sq = sqrt(disc);
+            double h = -0.5 * (p + (p >= 0.0 ? sq : -sq));
+            roots[1] = h;
+            roots[2] = h != 0.0 ? q / h : 0.0;
+            nroots = 3;
+        }
+    }
+    int nsol = 0;
+    for (int ri = 0; ri < nroots && nsol == 0; ri++) {
+        const double g = ri == 0 ? roots[0] : (ri == 1 ? roots[1] : roots[2]);
+        double D0[9], e[3], E[9];
+#pragma unroll
+        for (int k = 0; k < 9; k++) D0[k] = D1[k] + g * D2[k];
+        jacobi3(D0, e, E);
+        if (!(e[0] < 0.0 && e[2] > 0.0) || !(fabs(e[1]) <= fabs(e[0]) && fabs(e[1]) <= fabs(e[2]))) continue;
+        const double s = sqrt(-e[0] / e[2]);
+        const bool useD2 = fabs(g) <= 1.0;
+        double D[9];
+#pragma unroll
+        for (int k = 0; k < 9; k++) D[k] = useD2 ? D2[k] : D1[k];
+        for (int sign = 0; sign < 2; sign++) {
+            double w[3];
+#pragma unroll
+            for (int k = 0; k < 3; k++) w[k] = E[k * 3 + 2] + (sign ? -s : s) * E[k * 3 + 0];
+            int kk = 0;
+            if (fabs(w[1]) > fabs(sel3(w, kk))) kk = 1;
+            if (fabs(w[2]) > fabs(sel3(w, kk))) kk = 2;
+            const double wk = sel3(w, kk);
+            if (wk == 0.0) continue;
+            const int ii = kk == 0 ? 1 : 0, jj = kk == 2 ? 1 : 2;
+            const double al = -sel3(w, ii) / wk, be = -sel3(w, jj) / wk;
+            double p[3], q[3];
+#pragma unroll
+            for (int k = 0; k < 3; k++) { p[k] = (k == ii) ? 1.0 : ((k == kk) ? al : 0.0); q[k] = (k == jj) ? 1.0 : ((k == kk) ? be : 0.0); }
+            const double A = quad_form(D, p, p), B = 2.0 * quad_form(D, p, q), C = quad_form(D, q, q);
+            double taus[2] = { 0.0, 0.0 };
+            int nt = 0;
+            if (A == 0.0) { if (B != 0.0) { taus[0] = -C / B; nt = 1; } }
+            else {
+                double disc = B * B - 4.0 * A * C;
+                if (disc >= 0.0) {
+                    double sq = sqrt(disc);
+                    double h = -0.5 * (B + (B >= 0.0 ? sq : -sq));
+                    taus[0] = h / A; nt = 1;
+                    if (h != 0.0) { taus[1] = C / h; nt = 2; }
+                }
+            }
+            const int pr = ii + jj - 1;
+            const double bij = sel3(b, pr), aij = sel3(a, pr);
+            for (int ti = 0; ti < nt && nsol < 4; ti++) {
+                const double tau = ti == 0 ? taus[0] : taus[1];
+                if (!(tau > 0.0)) continue;
+                const double den = tau * tau + 1.0 - 2.0 * bij * tau;
+                if (!(den > 0.0)) continue;
+                const double Lj = sqrt(aij / den), Li = tau * Lj, Lk = al * Li + be * Lj;
+                if (!(Lk > 0.0)) continue;
+                double L[3];
+#pragma unroll
+                for (int k = 0; k < 3; k++) L[k] = (k == ii) ? Li : ((k == jj) ? Lj : Lk);
+                for (int it = 0; it < 5; it++) {
+                    double r0 = L[0] * L[0] + L[1] * L[1] - 2.0 * b[0] * L[0] * L[1] - a[0];
+                    double r1 = L[0] * L[0] + L[2] * L[2] - 2.0 * b[1] * L[0] * L[2] - a[1];
+                    double r2 = L[1] * L[1] + L[2] * L[2] - 2.0 * b[2] * L[1] * L[2] - a[2];
+                    const double Jm[9] = { 2.0 * L[0] - 2.0 * b[0] * L[1], 2.0 * L[1] - 2.0 * b[0] * L[0], 0.0,
+                                           2.0 * L[0] - 2.0 * b[1] * L[2], 0.0, 2.0 * L[2] - 2.0 * b[1] * L[0],
+                                           0.0, 2.0 * L[1] - 2.0 * b[2] * L[2], 2.0 * L[2] - 2.0 * b[2] * L[1] };
+                    double Ja[9];
+                    adj3s(Jm, Ja);
+                    double det = det3(Jm);
+                    if (det == 0.0) break;
+                    double id = 1.0 / det;
+                    L[0] -= (Ja[0] * r0 + Ja[1] * r1 + Ja[2] * r2) * id;
+                    L[1] -= (Ja[3] * r0 + Ja[4] * r1 + Ja[5] * r2) * id;
+                    L[2] -= (Ja[6] * r0 + Ja[7] * r1 + Ja[8] * r2) * id;
+                }
+                if (!(L[0] > 0.0 && L[1] > 0.0 && L[2] > 0.0)) continue;
+                double Y[9];
+#pragma unroll
+                for (int k = 0; k < 3; k++) { Y[k] = L[0] * f0[k]; Y[3 + k] = L[1] * f1[k]; Y[6 + k] = L[2] * f2[k]; }
+                double y1[3], y2[3], y3[3], x3[3];
+#pragma unroll
+                for (int k = 0; k < 3; k++) { y1[k] = Y[k] - Y[3 + k]; y2[k] = Y[k] - Y[6 + k]; }
+                y3[0] = y1[1] * y2[2] - y1[2] * y2[1]; y3[1] = y1[2] * y2[0] - y1[0] * y2[2]; y3[2] = y1[0] * y2[1] - y1[1] * y2[0];
+                x3[0] = d01[1] * d02[2] - d01[2] * d02[1]; x3[1] = d01[2] * d02[0] - d01[0] * d02[2]; x3[2] = d01[0] * d02[1] - d01[1] * d02[0];
+                const double Xm[9] = { d01[0], d02[0], x3[0], d01[1], d02[1], x3[1], d01[2], d02[2], x3[2] };
+                const double Ym[9] = { y1[0], y2[0], y3[0], y1[1], y2[1], y3[1], y1[2], y2[2], y3[2] };
+                double Xa[9];
+                adj3s(Xm, Xa);
+                double dx = det3(Xm);
+                if (dx == 0.0) continue;
+                double idx_ = 1.0 / dx;
+                double R[9], tt[3];
+#pragma unroll
+                for (int i = 0; i < 3; i++)
+#pragma unroll
+                    for (int j = 0; j < 3; j++)
+                        R[i * 3 + j] = (Ym[i * 3] * Xa[j] + Ym[i * 3 + 1] * Xa[3 + j] + Ym[i * 3 + 2] * Xa[6 + j]) * idx_;
+#pragma unroll
+                for (int i = 0; i < 3; i++) tt[i] = Y[i] - (R[i * 3] * X[0] + R[i * 3 + 1] * X[1] + R[i * 3 + 2] * X[2]);
+                // nsol is a small runtime index: write through a switch-free select loop
+#pragma unroll
+                for (int c = 0; c < 4; c++)
+                    if (c == nsol) {
+#pragma unroll
+                        for (int e = 0; e < 9; e++) Rout[c][e] = R[e];
+#pragma unroll
+                        for (int e = 0; e < 3; e++) tout[c][e] = tt[e];
+                    }
+                nsol++;
+            }
+        }
+    }
+    return nsol;
+}
+
+__global__ __launch_bounds__(64)
+void pnp_solve_k(PnpArgs a)
+{
+    const int b = blockIdx.y;
+    const int h = blockIdx.x * 64 + threadIdx.x;
+    if (h >= a.H) return;
+    const int P = a.P[b];
+    const double* Xw = a.X + (size_t)b * a.capP * 3;
+    const double* x = a.x + (size_t)b * a.capP * 2;
+    const double* xn = a.xn + (size_t)b * a.capP * 2;
+    const double* K = a.K + b * 9;
+    const double* k = a.dist + b * 8;
+    const int32_t* s = a.samples + ((size_t)b * a.H + h) * 4;
+    int si[4];
+    bool valid = P >= 4;
+#pragma unroll
+    for (int j = 0; j < 4; j++) { si[j] = s[j]; if (si[j] < 0 || si[j] >= P) { valid = false; si[j] = 0; } }
+    double f[9], Xs[9];
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        double bx = xn[2 * si[j]], by = xn[2 * si[j] + 1];
+        double inv = 1.0 / sqrt(bx * bx + by * by + 1.0);
+        f[3 * j] = bx * inv; f[3 * j + 1] = by * inv; f[3 * j + 2] = inv;
+        Xs[3 * j] = Xw[3 * si[j]]; Xs[3 * j + 1] = Xw[3 * si[j] + 1]; Xs[3 * j + 2] = Xw[3 * si[j] + 2];
+    }
+    double R[4][9], t[4][3];
+    const int n = valid ? p3p(f, Xs, R, t) : 0;
+    const bool has_dist = (k[0] != 0.0) | (k[1] != 0.0) | (k[2] != 0.0) | (k[3] != 0.0) | (k[4] != 0.0) | (k[5] != 0.0) | (k[6] != 0.0) | (k[7] != 0.0);
+    double bestRt[12];
+#pragma unroll
+    for (int e = 0; e < 12; e++) bestRt[e] = 0.0;
+    bool have = false;
+    double beste = 0.0;
+    const double X4 = Xw[3 * si[3]], Y4 = Xw[3 * si[3] + 1], Z4 = Xw[3 * si[3] + 2];
+    const double ox = x[2 * si[3]], oy = x[2 * si[3] + 1];
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        if (c < n) {
+            double cand[12];
+#pragma unroll
+            for (int i = 0; i < 3; i++) { cand[i * 4] = R[c][i * 3]; cand[i * 4 + 1] = R[c][i * 3 + 1]; cand[i * 4 + 2] = R[c][i * 3 + 2]; cand[i * 4 + 3] = t[c][i]; }
+            double u, v;
+            project_pt(cand, K[0], K[4], K[2], K[5], k, has_dist, X4, Y4, Z4, u, v);
+            double dx = u - ox, dy = v - oy;
+            double e = dx * dx + dy * dy;
+            if (e == e && (!have || e < beste)) {
+                have = true; beste = e;
+#pragma unroll
+                for (int q = 0; q < 12; q++) bestRt[q] = cand[q];
+            }
+        }
+    }
+    double* mo = a.models + ((size_t)b * a.H + h) * 12;
+#pragma unroll
+    for (int e = 0; e < 12; e++) mo[e] = bestRt[e]; // all zero = no hypothesis
+}
+
+template <bool HAS_DIST>
+__device__ __forceinline__ void pnp_score_body(const PnpArgs& a, int b, int h0, int tid, int lane, double (*s_Rt)[12], int* s_cnt)
+{
+    const int P = a.P[b];
+    const double* K = a.K + b * 9;
+    const double* k = a.dist + b * 8;
+    const double fx = K[0], fy = K[4], cx = K[2], cy = K[5];
+    int cnt[HT];
+#pragma unroll
+    for (int q = 0; q < HT; q++) cnt[q] = 0;
+    const double* Xw = a.X + (size_t)b * a.capP * 3;
+    const double* x = a.x + (size_t)b * a.capP * 2;
+    for (int i0 = 0; i0 < P; i0 += SCORE_THREADS) {
+        const int i = i0 + tid;
+        const bool live = i < P;
+        const int ic = live ? i : 0;
+        const double X = Xw[3 * ic], Y = Xw[3 * ic + 1], Z = Xw[3 * ic + 2];
+        const double ox = x[2 * ic], oy = x[2 * ic + 1];
+#pragma unroll
+        for (int q = 0; q < HT; q++) {
+            double u, v;
+            project_pt(s_Rt[q], fx, fy, cx, cy, k, HAS_DIST, X, Y, Z, u, v);
+            const double dx = ox - u, dy = oy - v;
+            // sqrt(d2) < thr  <=>  d2 < thr2cut  (thr2cut = smallest double whose sqrt is >= thr)
+            const bool in = live && (dx * dx + dy * dy < a.thr2cut);
+            cnt[q] += __popcll(__ballot(in));
+        }
+    }
+    if (lane == 0)
+#pragma unroll
+        for (int q = 0; q < HT; q++) atomicAdd(&s_cnt[q], cnt[q]);
+}
+
+__global__ __launch_bounds__(SCORE_THREADS)
+void pnp_score_k(PnpArgs a)
+{
+    const int b = blockIdx.y, h0 = blockIdx.x * HT, tid = threadIdx.x, lane = tid & 63;
+    __shared__ double s_Rt[HT][12];
+    __shared__ int s_cnt[HT];
+    __shared__ int s_valid[HT];
+    if (tid < HT * 12) {
+        int hh = tid / 12, e = tid % 12;
+        s_Rt[hh][e] = (h0 + hh < a.H) ? a.models[((size_t)b * a.H + h0 + hh) * 12 + e] : 0.0;
+    }
+    if (tid < HT) s_cnt[tid] = 0;
+    __syncthreads();
+    if (tid < HT) { // a hypothesis without a pose is all zero (row 2 of a rotation cannot be zero)
+        s_valid[tid] = !(s_Rt[tid][8] == 0.0 && s_Rt[tid][9] == 0.0 && s_Rt[tid][10] == 0.0);
+    }
+    const double* k = a.dist + b * 8;
+    const bool has_dist = (k[0] != 0.0) | (k[1] != 0.0) | (k[2] != 0.0) | (k[3] != 0.0) | (k[4] != 0.0) | (k[5] != 0.0) | (k[6] != 0.0) | (k[7] != 0.0);
+    if (has_dist) pnp_score_body<true>(a, b, h0, tid, lane, s_Rt, s_cnt);
+    else pnp_score_body<false>(a, b, h0, tid, lane, s_Rt, s_cnt);
+    __syncthreads();
+    if (tid < HT && h0 + tid < a.H) a.counts[(size_t)b * a.H + h0 + tid] = s_valid[tid] ? s_cnt[tid] : 0;
+}
+
+__device__ void R_to_rodrigues(const double* R, double* r)
+{
+    double rx = R[7] - R[5], ry = R[2] - R[6], rz = R[3] - R[1];
+    double s = sqrt((rx * rx + ry * ry + rz * rz) * 0.25);
+    double c = (R[0] + R[4] + R[8] - 1) * 0.5;
+    c = c > 1. ? 1. : (c < -1. ? -1. : c);
+    double th = acos(c);
+    if (s < 1e-5) {
+        if (c > 0) { r[0] = r[1] = r[2] = 0; return; }
+        double t;
+        t = (R[0] + 1) * 0.5; rx = sqrt(t > 0 ? t : 0);
+        t = (R[4] + 1) * 0.5; ry = sqrt(t > 0 ? t : 0) * (R[1] < 0 ? -1. : 1.);
+        t = (R[8] + 1) * 0.5; rz = sqrt(t > 0 ? t : 0) * (R[2] < 0 ? -1. : 1.);
+        if (fabs(rx) < fabs(ry) && fabs(rx) < fabs(rz) && (R[5] > 0) != (ry * rz > 0)) rz = -rz;
+        double nn = sqrt(rx * rx + ry * ry + rz * rz);
+        th /= nn;
+        r[0] = rx * th; r[1] = ry * th; r[2] = rz * th;
+        return;
+    }
+    double vth = 1 / (2 * s);
+    vth *= th;
+    r[0] = rx * vth; r[1] = ry * vth; r[2] = rz * vth;
+}
+
+__global__ __launch_bounds__(256)
+void pnp_finalize_k(PnpArgs a)
+{
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int P = a.P[b];
+    const int best = a.best[b];
+    const int bc = a.best_cnt[b];
+    uint8_t* mask = a.inliers + (size_t)b * a.capP;
+    double* Rt_out = a.Rt + (size_t)b * 12;
+    __shared__ double s_red[27 * 256];
+    __shared__ double s_Rt[12];
+    __shared__ int s_n, s_fail;
+    if (best < 0 || bc < a.min_inliers) {
+        for (int i = tid; i < P; i += 256) mask[i] = 0;
+        if (tid < 12) Rt_out[tid] = 0.0;
+        if (tid < 3) { if (a.rvec) a.rvec[b * 3 + tid] = 0.0; if (a.tvec) a.tvec[b * 3 + tid] = 0.0; }
+        if (tid == 0) { a.n_inliers[b] = 0; if (a.status) a.status[b] = MSLAM_ERR_DEGENERATE; }
+        return;
+    }
+    if (tid < 12) s_Rt[tid] = a.models[((size_t)b * a.H + best) * 12 + tid];
+    if (tid == 0) { s_n = 0; s_fail = 0; }
+    __syncthreads();
+    const double* K = a.K + b * 9;
+    const double* k = a.dist + b * 8;
+    const double fx = K[0], fy = K[4], cx = K[2], cy = K[5];
+    const bool has_dist = (k[0] != 0.0) | (k[1] != 0.0) | (k[2] != 0.0) | (k[3] != 0.0) | (k[4] != 0.0) | (k[5] != 0.0) | (k[6] != 0.0) | (k[7] != 0.0);
+    const double* Xw = a.X + (size_t)b * a.capP * 3;
+    const double* x = a.x + (size_t)b * a.capP * 2;
+    int my = 0;
+    for (int i = tid; i < P; i += 256) {
+        double u, v;
+        project_pt(s_Rt, fx, fy, cx, cy, k, has_dist, Xw[3 * i], Xw[3 * i + 1], Xw[3 * i + 2], u, v);
+        double dx = x[2 * i] - u, dy = x[2 * i + 1] - v;
+        bool in = dx * dx + dy * dy < a.thr2cut;
+        mask[i] = (uint8_t)in;
+        my += in;
+    }
+    atomicAdd(&s_n, my);
+    __syncthreads();
+    if (tid == 0) { a.n_inliers[b] = s_n; if (a.status) a.status[b] = MSLAM_OK; }
+    // ---- Gauss-Newton on the inliers: H (21 unique) and g (6) by block reduction, 6x6 Cholesky on lane 0
+    for (int it = 0; it < a.refine_iters; it++) {
+        double acc[27];
+#pragma unroll
+        for (int q = 0; q < 27; q++) acc[q] = 0.0;
+        for (int i = tid; i < P; i += 256) {
+            if (!mask[i]) continue;
+            const double Xi0 = Xw[3 * i], Xi1 = Xw[3 * i + 1], Xi2 = Xw[3 * i + 2];
+            double px = s_Rt[0] * Xi0 + s_Rt[1] * Xi1 + s_Rt[2] * Xi2 + s_Rt[3];
+            double py = s_Rt[4] * Xi0 + s_Rt[5] * Xi1 + s_Rt[6] * Xi2 + s_Rt[7];
+            double pz = s_Rt[8] * Xi0 + s_Rt[9] * Xi1 + s_Rt[10] * Xi2 + s_Rt[11];
+            if (pz == 0.0) continue;
+            double iz = 1.0 / pz, xx = px * iz, yy = py * iz;
+            double r2 = xx * xx + yy * yy, r4 = r2 * r2, r6 = r4 * r2;
+            double cd = 1 + k[0] * r2 + k[1] * r4 + k[4] * r6;
+            double icd2 = 1. / (1 + k[5] * r2 + k[6] * r4 + k[7] * r6);
+            double xd = xx * cd * icd2 + k[2] * 2 * xx * yy + k[3] * (r2 + 2 * xx * xx);
+            double yd = yy * cd * icd2 + k[2] * (r2 + 2 * yy * yy) + k[3] * 2 * xx * yy;
+            double ru = x[2 * i] - (xd * fx + cx), rv = x[2 * i + 1] - (yd * fy + cy);
+            double dcd = k[0] + 2 * k[1] * r2 + 3 * k[4] * r4;
+            double dicd = -(k[5] + 2 * k[6] * r2 + 3 * k[7] * r4) * icd2 * icd2;
+            double rad = cd * icd2, drad = dcd * icd2 + cd * dicd;
+            double dxx = rad + xx * drad * 2 * xx + 2 * k[2] * yy + k[3] * (2 * xx + 4 * xx);
+            double dxy = xx * drad * 2 * yy + 2 * k[2] * xx + k[3] * 2 * yy;
+            double dyx = yy * drad * 2 * xx + k[2] * 2 * xx + 2 * k[3] * yy;
+            double dyy = rad + yy * drad * 2 * yy + k[2] * (2 * yy + 4 * yy) + 2 * k[3] * xx;
+            double a00 = iz, a02 = -xx * iz, a11 = iz, a12 = -yy * iz;
+            double m[6];
+            m[0] = fx * (dxx * a00); m[1] = fx * (dxy * a11); m[2] = fx * (dxx * a02 + dxy * a12);
+            m[3] = fy * (dyx * a00); m[4] = fy * (dyy * a11); m[5] = fy * (dyx * a02 + dyy * a12);
+            double Ju[6], Jv[6];
+            Ju[0] = m[1] * (-pz) + m[2] * (py); Ju[1] = m[0] * (pz) + m[2] * (-px); Ju[2] = m[0] * (-py) + m[1] * (px);
+            Ju[3] = m[0]; Ju[4] = m[1]; Ju[5] = m[2];
+            Jv[0] = m[4] * (-pz) + m[5] * (py); Jv[1] = m[3] * (pz) + m[5] * (-px); Jv[2] = m[3] * (-py) + m[4] * (px);
+            Jv[3] = m[3]; Jv[4] = m[4]; Jv[5] = m[5];
+            int q = 0;
+#pragma unroll
+            for (int r = 0; r < 6; r++)
+#pragma unroll
+                for (int c = r; c < 6; c++) acc[q++] += Ju[r] * Ju[c] + Jv[r] * Jv[c];
+#pragma unroll
+            for (int r = 0; r < 6; r++) acc[21 + r] += Ju[r] * ru + Jv[r] * rv;
+        }
+        block_reduce<27>(acc, s_red, tid);
+        if (tid == 0) {
+            double Hm[36], g[6], Lc[36], yv[6], d[6];
+            int q = 0;
+            for (int r = 0; r < 6; r++) for (int c = r; c < 6; c++) { Hm[r * 6 + c] = acc[q]; Hm[c * 6 + r] = acc[q]; q++; }
+            for (int r = 0; r < 6; r++) g[r] = acc[21 + r];
+            bool ok = true;
+            for (int i = 0; i < 36; i++) Lc[i] = 0.0;
+            for (int i = 0; i < 6 && ok; i++)
+                for (int j = 0; j <= i; j++) {
+                    double sum = Hm[i * 6 + j];
+                    for (int w = 0; w < j; w++) sum -= Lc[i * 6 + w] * Lc[j * 6 + w];
+                    if (i == j) { if (!(sum > 0.0)) { ok = false; break; } Lc[i * 6 + i] = sqrt(sum); }
+                    else Lc[i * 6 + j] = sum / Lc[j * 6 + j];
+                }
+            if (!ok) s_fail = 1;
+            else {
+                for (int i = 0; i < 6; i++) { double sum = g[i]; for (int w = 0; w < i; w++) sum -= Lc[i * 6 + w] * yv[w]; yv[i] = sum / Lc[i * 6 + i]; }
+                for (int i = 5; i >= 0; i--) { double sum = yv[i]; for (int w = i + 1; w < 6; w++) sum -= Lc[w * 6 + i] * d[w]; d[i] = sum / Lc[i * 6 + i]; }
+                double th2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2], th = sqrt(th2);
+                double A_, B_, C_;
+                if (th < 1e-8) { A_ = 1.0; B_ = 0.5; C_ = 1.0 / 6.0; }
+                else { A_ = sin(th) / th; B_ = (1 - cos(th)) / th2; C_ = (th - sin(th)) / (th2 * th); }
+                const double Om[9] = { 0, -d[2], d[1], d[2], 0, -d[0], -d[1], d[0], 0 };
+                double Om2[9], dR[9], V[9], nRt[12];
+                for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { double s = 0; for (int w = 0; w < 3; w++) s += Om[i * 3 + w] * Om[w * 3 + j]; Om2[i * 3 + j] = s; }
+                for (int i = 0; i < 9; i++) { double I = (i % 4 == 0) ? 1.0 : 0.0; dR[i] = I + A_ * Om[i] + B_ * Om2[i]; V[i] = I + B_ * Om[i] + C_ * Om2[i]; }
+                for (int i = 0; i < 3; i++) {
+                    for (int j = 0; j < 4; j++) nRt[i * 4 + j] = dR[i * 3] * s_Rt[j] + dR[i * 3 + 1] * s_Rt[4 + j] + dR[i * 3 + 2] * s_Rt[8 + j];
+                    nRt[i * 4 + 3] += V[i * 3] * d[3] + V[i * 3 + 1] * d[4] + V[i * 3 + 2] * d[5];
+                }
+                for (int i = 0; i < 12; i++) s_Rt[i] = nRt[i];
+            }
+        }
+        __syncthreads();
+        if (s_fail) break;
+    }
+    if (tid == 0) {
+        for (int i = 0; i < 12; i++) Rt_out[i] = s_Rt[i];
+        const double R[9] = { s_Rt[0], s_Rt[1], s_Rt[2], s_Rt[4], s_Rt[5], s_Rt[6], s_Rt[8], s_Rt[9], s_Rt[10] };
+        if (a.rvec) R_to_rodrigues(R, a.rvec + b * 3);
+        if (a.tvec) { a.tvec[b * 3] = s_Rt[3]; a.tvec[b * 3 + 1] = s_Rt[7]; a.tvec[b * 3 + 2] = s_Rt[11]; }
+    }
+}
+
+// ------------------------------------------------------------------ triangulation (R11)
+struct TriArgs { const double* x1; const double* x2; int n; double P1[12], P2[12], Rt1[12], Rt2[12]; double* X; uint8_t* front; int32_t* n_front; };
+
+// symmetric 4x4 Jacobi in registers is awkward; the 4x4 problem is done per lane in scratch memory
+__global__ __launch_bounds__(64)
+void triangulate_k(TriArgs a)
+{
+    const int p = blockIdx.x * 64 + threadIdx.x;
+    bool f = false;
+    if (p < a.n) {
+        double A[16];
+        for (int j = 0; j < 4; j++) {
+            A[0 * 4 + j] = a.P1[0 * 4 + j] - a.P1[2 * 4 + j] * a.x1[2 * p];
+            A[1 * 4 + j] = a.P1[1 * 4 + j] - a.P1[2 * 4 + j] * a.x1[2 * p + 1];
+            A[2 * 4 + j] = a.P2[0 * 4 + j] - a.P2[2 * 4 + j] * a.x2[2 * p];
+            A[3 * 4 + j] = a.P2[1 * 4 + j] - a.P2[2 * 4 + j] * a.x2[2 * p + 1];
+        }
+        double AtA[16], w[4], V[16];
+        for (int i = 0; i < 4; i++)
+            for (int j = 0; j < 4; j++) {
+                double acc = 0;
+                for (int k = 0; k < 4; k++) acc += A[k * 4 + i] * A[k * 4 + j];
+                AtA[i * 4 + j] = acc;
+            }
+        jacobi_mem(AtA, 4, w, V);
+        const int k0 = argmin_first(w, 4);
+        const double Xh[4] = { V[0 * 4 + k0], V[1 * 4 + k0], V[2 * 4 + k0], V[3 * 4 + k0] };
+        const double X0 = Xh[0] / Xh[3], X1 = Xh[1] / Xh[3], X2 = Xh[2] / Xh[3];
+        a.X[3 * p] = X0; a.X[3 * p + 1] = X1; a.X[3 * p + 2] = X2;
+        double z1 = a.Rt1[8] * X0 + a.Rt1[9] * X1 + a.Rt1[10] * X2 + a.Rt1[11];
+        double z2 = a.Rt2[8] * X0 + a.Rt2[9] * X1 + a.Rt2[10] * X2 + a.Rt2[11];
+        f = z1 > 0 && z2 > 0;
+        if (a.front) a.front[p] = (uint8_t)f;
+    }
+    unsigned long long bal = __ballot(f);
+    if (threadIdx.x == 0 && bal) atomicAdd(a.n_front, __popcll(bal));
+}
+
+// smallest double t with sqrt(t) >= thr, so that (sqrt(d2) < thr) == (d2 < t) for every d2
+double sqrt_cut(double thr)
+{
+    if (!(thr > 0.0)) return 0.0;
+    double t = thr * thr;
+    while (std::sqrt(t) >= thr) t = std::nextafter(t, 0.0);
+    while (std::sqrt(t) < thr) t = std::nextafter(t, INFINITY);
+    return t;
+}
+
+} // namespace
+
+extern "C" {
+
+void mslam_fmat_default_params(mslam_fmat_params* p)
+{
+    if (!p) return;
+    p->metric = 1; p->threshold = 3.0; p->confidence = 0.85; p->refit = 2; // src/ParamConfig.h:24-25
+}
+
+void mslam_pnp_default_params(mslam_pnp_params* p)
+{
+    if (!p) return;
+    p->reproj_thr = 8.0; p->confidence = 0.0; p->refine_iters = 10; p->min_inliers = 4;
+}
+
+int mslam_fmat_ransac8_batch_dev(mslam_ctx* ctx, const double* x1, const double* x2, const int32_t* M, int capM,
+                                 const int32_t* samples, int H, int B, const mslam_fmat_params* prm, double* F,
+                                 uint8_t* status, int32_t* inlier_counts, int32_t* best_h, int32_t* n_inliers)
+{
+    if (!ctx || !x1 || !x2 || !M || !samples || !prm || !F || !status || !best_h || !n_inliers || capM < 8 || H < 1 || B < 1 ||
+        (prm->metric != 0 && prm->metric != 1) || prm->refit < 0 || prm->refit > 2 || !(prm->threshold > 0))
+        return MSLAM_ERR_INVALID;
+    MSLAM_TRY(ctx_set_device(ctx));
+    size_t bytes = 0;
+    auto reserve = [&](size_t n) { bytes = align_up(bytes, 256); size_t o = bytes; bytes += n; return o; };
+    const size_t o_pts = reserve(sizeof(double) * 4 * (size_t)B * capM), o_maxt = reserve(sizeof(double) * B),
+                 o_mod = reserve(sizeof(double) * 9 * (size_t)B * H), o_mods = reserve(sizeof(double) * 9 * (size_t)B * H),
+                 o_cnt = reserve(sizeof(int32_t) * (size_t)B * H);
+    void* scr = nullptr;
+    MSLAM_TRY(ctx_scratch(ctx, bytes, &scr));
+    char* base = (char*)scr;
+    FmatArgs a{};
+    a.x1 = x1; a.x2 = x2; a.M = M; a.capM = capM; a.samples = samples; a.H = H; a.B = B;
+    a.metric = prm->metric; a.thr = prm->metric == 0 ? prm->threshold : prm->threshold * prm->threshold;
+    a.confidence = prm->confidence; a.refit = prm->refit;
+    a.pts = (double*)(base + o_pts); a.maxt = (double*)(base + o_maxt); a.models = (double*)(base + o_mod);
+    a.models_s = (double*)(base + o_mods);
+    a.counts = inlier_counts ? inlier_counts : (int32_t*)(base + o_cnt);
+    a.best = best_h; a.F = F; a.status = status; a.n_inliers = n_inliers;
+    hipStream_t st = ctx->stream;
+    hipLaunchKernelGGL(fmat_prepare_k, dim3(B), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(fmat_solve_k, dim3((H + 63) / 64, B), dim3(64), 0, st, a);
+    hipLaunchKernelGGL(fmat_score_k, dim3((H + HT - 1) / HT, B), dim3(SCORE_THREADS), 0, st, a);
+    hipLaunchKernelGGL(ransac_select_k, dim3(B), dim3(64), 0, st, a.counts, M, H, 8, prm->confidence, best_h, (int32_t*)nullptr);
+    hipLaunchKernelGGL(fmat_finalize_k, dim3(B), dim3(256), 0, st, a);
+    HIP_TRY(ctx, hipGetLastError());
+    return MSLAM_OK;
+}
+
+int mslam_fmat_ransac8(mslam_ctx* ctx, const double* x1, const double* x2, int M, const int32_t* samples, int H,
+                       const mslam_fmat_params* prm, double F[9], uint8_t* status, int32_t* inlier_counts, int* best_h,
+                       int* n_inliers)
+{
+    if (!ctx || !x1 || !x2 || !samples || !prm || !F || !status) return MSLAM_ERR_INVALID;
+    if (M < 8 || H < 1) return MSLAM_ERR_TOO_FEW;
+    MSLAM_TRY(ctx_set_device(ctx));
+    size_t bytes = 0;
+    auto reserve = [&](size_t n) { bytes = align_up(bytes, 256); size_t o = bytes; bytes += n; return o; };
+    const size_t o_x1 = reserve(sizeof(double) * 2 * M), o_x2 = reserve(sizeof(double) * 2 * M), o_M = reserve(16),
+                 o_s = reserve(sizeof(int32_t) * 8 * (size_t)H), o_F = reserve(72), o_st = reserve(M),
+                 o_c = reserve(sizeof(int32_t) * (size_t)H), o_b = reserve(16);
+    void* stg = nullptr;
+    MSLAM_TRY(ctx_stage(ctx, bytes, &stg));
+    char* base = (char*)stg;
+    hipStream_t st = ctx->stream;
+    int32_t hM = M;
+    HIP_TRY(ctx, hipMemcpyAsync(base + o_x1, x1, sizeof(double) * 2 * M, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(base + o_x2, x2, sizeof(double) * 2 * M, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(base + o_M, &hM, 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(base + o_s, samples, sizeof(int32_t) * 8 * (size_t)H, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    int32_t* db = (int32_t*)(base + o_b);
+    MSLAM_TRY(mslam_fmat_ransac8_batch_dev(ctx, (double*)(base + o_x1), (double*)(base + o_x2), (int32_t*)(base + o_M), M,
+                                           (int32_t*)(base + o_s), H, 1, prm, (double*)(base + o_F), (uint8_t*)(base + o_st),
+                                           (int32_t*)(base + o_c), db, db + 1));
+    int32_t hb[2] = { -1, 0 };
+    HIP_TRY(ctx, hipMemcpyAsync(hb, db, 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipMemcpyAsync(F, base + o_F, 72, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipMemcpyAsync(status, base + o_st, M, hipMemcpyDeviceToHost, st));
+    if (inlier_counts) HIP_TRY(ctx, hipMemcpyAsync(inlier_counts, base + o_c, sizeof(int32_t) * (size_t)H, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    if (best_h) *best_h = hb[0];
+    if (n_inliers) *n_inliers = hb[1];
+    if (hb[0] < 0) return MSLAM_ERR_DEGENERATE;
+    return MSLAM_OK;
+}
+
+int mslam_pnp_ransac_batch_dev(mslam_ctx* ctx, const double* X, const double* x, const int32_t* P, int capP,
+                               const double* K, const double* dist, const int32_t* samples, int H, int B,
+                               const mslam_pnp_params* prm, double* Rt, double* rvec, double* tvec, uint8_t* inliers,
+                               int32_t* inlier_counts, int32_t* best_h, int32_t* n_inliers)
+{
+    if (!ctx || !X || !x || !P || !K || !dist || !samples || !prm || !Rt || !inliers || !best_h || !n_inliers || capP < 4 ||
+        H < 1 || B < 1 || !(prm->reproj_thr > 0) || prm->refine_iters < 0)
+        return MSLAM_ERR_INVALID;
+    MSLAM_TRY(ctx_set_device(ctx));
+    size_t bytes = 0;
+    auto reserve = [&](size_t n) { bytes = align_up(bytes, 256); size_t o = bytes; bytes += n; return o; };
+    const size_t o_xn = reserve(sizeof(double) * 2 * (size_t)B * capP), o_mod = reserve(sizeof(double) * 12 * (size_t)B * H),
+                 o_cnt = reserve(sizeof(int32_t) * (size_t)B * H), o_bc = reserve(sizeof(int32_t) * B);
+    void* scr = nullptr;
+    MSLAM_TRY(ctx_scratch(ctx, bytes, &scr));
+    char* base = (char*)scr;
+    PnpArgs a{};
+    a.X = X; a.x = x; a.P = P; a.capP = capP; a.K = K; a.dist = dist; a.samples = samples; a.H = H; a.B = B;
+    a.thr = prm->reproj_thr; a.thr2cut = sqrt_cut(prm->reproj_thr); a.confidence = prm->confidence;
+    a.refine_iters = prm->refine_iters; a.min_inliers = prm->min_inliers;
+    a.xn = (double*)(base + o_xn); a.models = (double*)(base + o_mod);
+    a.counts = inlier_counts ? inlier_counts : (int32_t*)(base + o_cnt);
+    a.best = best_h; a.best_cnt = (int32_t*)(base + o_bc);
+    a.Rt = Rt; a.rvec = rvec; a.tvec = tvec; a.inliers = inliers; a.n_inliers = n_inliers; a.status = nullptr;
+    hipStream_t st = ctx->stream;
+    hipLaunchKernelGGL(pnp_prepare_k, dim3((capP + 255) / 256, B), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(pnp_solve_k, dim3((H + 63) / 64, B), dim3(64), 0, st, a);
+    hipLaunchKernelGGL(pnp_score_k, dim3((H + HT - 1) / HT, B), dim3(SCORE_THREADS), 0, st, a);
+    hipLaunchKernelGGL(ransac_select_k, dim3(B), dim3(64), 0, st, a.counts, P, H, 4, prm->confidence, best_h, a.best_cnt);
+    hipLaunchKernelGGL(pnp_finalize_k, dim3(B), dim3(256), 0, st, a);
+    HIP_TRY(ctx, hipGetLastError());
+    return MSLAM_OK;
+}
+
+int mslam_pnp_ransac(mslam_ctx* ctx, const double* X, const double* x, int P, const double K[9], const double dist[8],
+                     const int32_t* samples, int H, const mslam_pnp_params* prm, double rvec[3], double tvec[3],
+                     double Rt[12], uint8_t* inliers, int32_t* inlier_counts, int* best_h, int* n_inliers)
+{
+    if (!ctx || !X || !x || !K || !dist || !samples || !prm || !inliers) return MSLAM_ERR_INVALID;
+    if (P < 4 || H < 1) return MSLAM_ERR_TOO_FEW;
+    MSLAM_TRY(ctx_set_device(ctx));
+    size_t bytes = 0;
+    auto reserve = [&](size_t n) { bytes = align_up(bytes, 256); size_t o = bytes; bytes += n; return o; };
+    const size_t o_X = reserve(sizeof(double) * 3 * P), o_x = reserve(sizeof(double) * 2 * P), o_P = reserve(16), o_K = reserve(72),
+                 o_d = reserve(64), o_s = reserve(sizeof(int32_t) * 4 * (size_t)H), o_Rt = reserve(96), o_r = reserve(24),
+                 o_t = reserve(24), o_in = reserve(P), o_c = reserve(sizeof(int32_t) * (size_t)H), o_b = reserve(16);
+    void* stg = nullptr;
+    MSLAM_TRY(ctx_stage(ctx, bytes, &stg));
+    char* base = (char*)stg;
+    hipStream_t st = ctx->stream;
+    int32_t hP = P;
+    HIP_TRY(ctx, hipMemcpyAsync(base + o_X, X, sizeof(double) * 3 * P, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(base + o_x, x, sizeof(double) * 2 * P, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(base + o_P, &hP, 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(base + o_K, K, 72, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(base + o_d, dist, 64, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(base + o_s, samples, sizeof(int32_t) * 4 * (size_t)H, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    int32_t* db = (int32_t*)(base + o_b);
+    MSLAM_TRY(mslam_pnp_ransac_batch_dev(ctx, (double*)(base + o_X), (double*)(base + o_x), (int32_t*)(base + o_P), P,
+                                         (double*)(base + o_K), (double*)(base + o_d), (int32_t*)(base + o_s), H, 1, prm,
+                                         (double*)(base + o_Rt), (double*)(base + o_r), (double*)(base + o_t),
+                                         (uint8_t*)(base + o_in), (int32_t*)(base + o_c), db, db + 1));
+    int32_t hb[2] = { -1, 0 };
+    double hRt[12], hr[3], ht[3];
+    HIP_TRY(ctx, hipMemcpyAsync(hb, db, 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipMemcpyAsync(hRt, base + o_Rt, 96, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipMemcpyAsync(hr, base + o_r, 24, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipMemcpyAsync(ht, base + o_t, 24, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipMemcpyAsync(inliers, base + o_in, P, hipMemcpyDeviceToHost, st));
+    if (inlier_counts) HIP_TRY(ctx, hipMemcpyAsync(inlier_counts, base + o_c, sizeof(int32_t) * (size_t)H, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    if (best_h) *best_h = hb[0];
+    if (n_inliers) *n_inliers = hb[1];
+    if (Rt) for (int i = 0; i < 12; i++) Rt[i] = hRt[i];
+    if (rvec) for (int i = 0; i < 3; i++) rvec[i] = hr[i];
+    if (tvec) for (int i = 0; i < 3; i++) tvec[i] = ht[i];
+    if (hb[0] < 0 || hb[1] < prm->min_inliers) return MSLAM_ERR_DEGENERATE;
+    return MSLAM_OK;
+}
+
+int mslam_triangulate(mslam_ctx* ctx, const double* x1, const double* x2, int n, const double Rt1[12], const double Rt2[12],
+                      const double K1[9], const double K2[9], double* X, uint8_t* front, int* n_front)
+{
+    if (!ctx || !x1 || !x2 || !Rt1 || !Rt2 || !K1 || !K2 || !X || n < 0) return MSLAM_ERR_INVALID;
+    if (n_front) *n_front = 0;
+    if (n == 0) return MSLAM_OK;
+    MSLAM_TRY(ctx_set_device(ctx));
+    size_t bytes = 0;
+    auto reserve = [&](size_t m) { bytes = align_up(bytes, 256); size_t o = bytes; bytes += m; return o; };
+    const size_t o_x1 = reserve(sizeof(double) * 2 * n), o_x2 = reserve(sizeof(double) * 2 * n), o_X = reserve(sizeof(double) * 3 * n),
+                 o_f = reserve(n), o_n = reserve(16);
+    void* stg = nullptr;
+    MSLAM_TRY(ctx_stage(ctx, bytes, &stg));
+    char* base = (char*)stg;
+    hipStream_t st = ctx->stream;
+    TriArgs a{};
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 4; j++) { // P = K * Rt (:91)
+            double p1 = 0, p2 = 0;
+            for (int k = 0; k < 3; k++) { p1 += K1[i * 3 + k] * Rt1[k * 4 + j]; p2 += K2[i * 3 + k] * Rt2[k * 4 + j]; }
+            a.P1[i * 4 + j] = p1; a.P2[i * 4 + j] = p2;
+        }
+    for (int i = 0; i < 12; i++) { a.Rt1[i] = Rt1[i]; a.Rt2[i] = Rt2[i]; }
+    a.x1 = (double*)(base + o_x1); a.x2 = (double*)(base + o_x2); a.n = n; a.X = (double*)(base + o_X);
+    a.front = (uint8_t*)(base + o_f); a.n_front = (int32_t*)(base + o_n);
+    HIP_TRY(ctx, hipMemcpyAsync(base + o_x1, x1, sizeof(double) * 2 * n, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(base + o_x2, x2, sizeof(double) * 2 * n, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemsetAsync(base + o_n, 0, 16, st));
+    hipLaunchKernelGGL(triangulate_k, dim3((n + 63) / 64), dim3(64), 0, st, a);
+    HIP_TRY(ctx, hipGetLastError());
+    int32_t hn = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(X, base + o_X, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, st));
+    if (front) HIP_TRY(ctx, hipMemcpyAsync(front, base + o_f, n, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipMemcpyAsync(&hn, base + o_n, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    if (n_front) *n_front = hn;
+    return MSLAM_OK;
+}
+
+} // extern "C"

@@ -141,3 +141,61 @@ def ratio_filter(idx, dist, ratio: float):
     n = C.c_int(0)
     lib().orc_ratio_filter(_p(idx, i32p), _p(dist, i32p), nq, C.c_float(ratio), _p(qi, i32p), _p(ti, i32p), _p(d, f32p), C.byref(n))
     return qi[: n.value].copy(), ti[: n.value].copy(), d[: n.value].copy()
+
+
+def fmat_default_params() -> FmatParams:
+    p = FmatParams()
+    lib().orc_fmat_default_params(C.byref(p))
+    return p
+
+
+def pnp_default_params() -> PnpParams:
+    p = PnpParams()
+    lib().orc_pnp_default_params(C.byref(p))
+    return p
+
+
+def fmat_ransac8(x1, x2, samples, params: FmatParams):
+    x1 = np.ascontiguousarray(x1, np.float64); x2 = np.ascontiguousarray(x2, np.float64)
+    samples = np.ascontiguousarray(samples, np.int32)
+    M, H = x1.shape[0], samples.shape[0]
+    F = np.zeros(9); status = np.zeros(M, np.uint8); counts = np.zeros(H, np.int32)
+    best, ninl = C.c_int(-1), C.c_int(0)
+    rc = lib().orc_fmat_ransac8(_p(x1, f64p), _p(x2, f64p), M, _p(samples, i32p), H, C.byref(params), _p(F, f64p),
+                                _p(status, u8p), _p(counts, i32p), C.byref(best), C.byref(ninl))
+    return dict(rc=rc, F=F.reshape(3, 3), status=status, counts=counts, best_h=best.value, n_inliers=ninl.value)
+
+
+def pnp_ransac(X, x, K, dist, samples, params: PnpParams):
+    X = np.ascontiguousarray(X, np.float64); x = np.ascontiguousarray(x, np.float64)
+    K = np.ascontiguousarray(K, np.float64); dist = np.ascontiguousarray(dist, np.float64)
+    samples = np.ascontiguousarray(samples, np.int32)
+    P, H = X.shape[0], samples.shape[0]
+    rvec, tvec, Rt = np.zeros(3), np.zeros(3), np.zeros(12)
+    inl = np.zeros(P, np.uint8); counts = np.zeros(H, np.int32)
+    best, ninl = C.c_int(-1), C.c_int(0)
+    rc = lib().orc_pnp_ransac(_p(X, f64p), _p(x, f64p), P, _p(K, f64p), _p(dist, f64p), _p(samples, i32p), H,
+                              C.byref(params), _p(rvec, f64p), _p(tvec, f64p), _p(Rt, f64p), _p(inl, u8p),
+                              _p(counts, i32p), C.byref(best), C.byref(ninl))
+    return dict(rc=rc, rvec=rvec, tvec=tvec, Rt=Rt.reshape(3, 4), inliers=inl, counts=counts, best_h=best.value,
+                n_inliers=ninl.value)
+
+
+def triangulate(x1, x2, Rt1, Rt2, K1, K2):
+    x1 = np.ascontiguousarray(x1, np.float64); x2 = np.ascontiguousarray(x2, np.float64)
+    n = x1.shape[0]
+    X = np.zeros((n, 3)); front = np.zeros(n, np.uint8); nf = C.c_int(0)
+    a = [np.ascontiguousarray(m, np.float64) for m in (Rt1, Rt2, K1, K2)]
+    lib().orc_triangulate(_p(x1, f64p), _p(x2, f64p), n, _p(a[0], f64p), _p(a[1], f64p), _p(a[2], f64p), _p(a[3], f64p),
+                          _p(X, f64p), _p(front, u8p), C.byref(nf))
+    return X, front, nf.value
+
+
+def pose_from_F(F, K1, K2, x1, x2):
+    x1 = np.ascontiguousarray(x1, np.float64); x2 = np.ascontiguousarray(x2, np.float64)
+    n = x1.shape[0]
+    a = [np.ascontiguousarray(m, np.float64) for m in (F, K1, K2)]
+    Rt = np.zeros(12); X = np.zeros((n, 3)); counts = np.zeros(4, np.int32)
+    best = lib().orc_pose_from_F(_p(a[0], f64p), _p(a[1], f64p), _p(a[2], f64p), _p(x1, f64p), _p(x2, f64p), n,
+                                 _p(Rt, f64p), _p(X, f64p), _p(counts, i32p))
+    return best, Rt.reshape(3, 4), X, counts

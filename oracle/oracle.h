@@ -70,6 +70,8 @@ void orc_jacobi_eig(const double* A, int n, double* w, double* V);
 /* SVD of a 3x3 (A = U diag(s) Vt, s descending, via eig of A^T A) */
 void orc_svd3(const double A[9], double U[9], double s[3], double Vt[9]);
 double orc_det3(const double A[9]);
+/* null vector of an 8x9 system by Gauss-Jordan with complete pivoting (A destroyed); 0 if rank-deficient */
+int orc_null_8x9(double* A, double f[9]);
 
 /* ---------------- fundamental matrix (reference src/CameraPoseEstimator.cpp:545-786) */
 typedef struct { int metric; double threshold; double confidence; int refit; } orc_fmat_params;

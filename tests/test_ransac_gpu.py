@@ -1,0 +1,160 @@
+"""K8 parity: HIP RANSAC (F eight-point, PnP/P3P) and triangulation vs the oracle.
+
+Integer outputs (inlier counts per hypothesis, winner, masks) must be identical; model floats
+within 1e-9 relative of the oracle's (north_star asks 1e-4)."""
+import numpy as np
+import pytest
+
+from monocular_slam_amd import api, synth
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-9
+
+
+def _fp(oracle, p):
+    op = oracle.fmat_default_params()
+    for f, _ in api.FmatParams._fields_:
+        setattr(op, f, getattr(p, f))
+    return op
+
+
+def _pp(oracle, p):
+    op = oracle.pnp_default_params()
+    for f, _ in api.PnpParams._fields_:
+        setattr(op, f, getattr(p, f))
+    return op
+
+
+def _close(a, b, rtol=RTOL):
+    scale = max(1e-300, float(np.abs(b).max()))
+    assert np.abs(np.asarray(a) - np.asarray(b)).max() <= rtol * scale, (a, b)
+
+
+@pytest.mark.parametrize("metric,thr,refit,conf", [(1, 3.0, 2, 0.85), (1, 3.0, 2, 0.0), (1, 1.5, 0, 0.99),
+                                                   (0, 0.001, 1, 0.0), (0, 0.1, 1, 0.85), (1, 3.0, 1, 0.5)])
+def test_fmat_ransac8_matches_oracle(ctx, oracle, metric, thr, refit, conf):
+    tv = synth.two_view_problem(500, 11)
+    S = synth.sample_table(500, 2000, 8, 5)
+    p = api.default_fmat_params()
+    p.metric, p.threshold, p.refit, p.confidence = metric, thr, refit, conf
+    g = ctx.fmat_ransac8(tv["x1"], tv["x2"], S, p)
+    o = oracle.fmat_ransac8(tv["x1"], tv["x2"], S, _fp(oracle, p))
+    assert g["rc"] == 0 and o["rc"] == 0
+    np.testing.assert_array_equal(g["counts"], o["counts"])
+    assert g["best_h"] == o["best_h"] and g["n_inliers"] == o["n_inliers"]
+    np.testing.assert_array_equal(g["status"], o["status"])
+    _close(g["F"], o["F"], 1e-7)   # refit goes through an ill-conditioned 9x9 eigenproblem
+
+
+def test_fmat_c2_size(ctx, oracle):
+    """C2-analogue: 2000 matches, 4096 hypotheses."""
+    tv = synth.two_view_problem(2000, 21, K=synth.K_MINITAUR, w=1920, h=1080)
+    S = synth.sample_table(2000, 4096, 8, 6)
+    p = api.default_fmat_params()
+    p.confidence = 0.0
+    g = ctx.fmat_ransac8(tv["x1"], tv["x2"], S, p)
+    o = oracle.fmat_ransac8(tv["x1"], tv["x2"], S, _fp(oracle, p))
+    np.testing.assert_array_equal(g["counts"], o["counts"])
+    assert g["best_h"] == o["best_h"]
+    np.testing.assert_array_equal(g["status"], o["status"])
+    _close(g["F"], o["F"], 1e-7)
+    # the model is geometrically right: inlier mask agrees with the ground truth
+    assert (g["status"].astype(bool) == ~tv["outlier"]).mean() > 0.95
+
+
+def test_fmat_too_few_and_degenerate(ctx):
+    p = api.default_fmat_params()
+    x = np.random.default_rng(0).uniform(0, 600, (7, 2))
+    with pytest.raises(api.MslamError) as e:
+        ctx.fmat_ransac8(x, x, np.zeros((4, 8), np.int32), p)
+    assert e.value.status == api.ERR_TOO_FEW
+    # all points identical: every hypothesis is rank deficient -> no model
+    x1 = np.full((20, 2), 100.0)
+    S = synth.sample_table(20, 16, 8, 1)
+    g = ctx.fmat_ransac8(x1, x1, S, p)
+    assert g["rc"] == api.ERR_DEGENERATE and g["best_h"] == -1
+
+
+@pytest.mark.parametrize("use_dist,thr,conf", [(False, 2.0, 0.0), (True, 2.0, 0.0), (False, 8.0, 0.99), (True, 8.0, 0.9)])
+def test_pnp_ransac_matches_oracle(ctx, oracle, use_dist, thr, conf):
+    """C2: 2000 correspondences, 4096 hypotheses, 30 % outliers."""
+    if use_dist:
+        pr = synth.pnp_problem(2000, 3003, K=synth.K_TUM1, dist=synth.DIST_TUM1, w=640, h=480)
+    else:
+        pr = synth.pnp_problem(2000, 3003)
+    S = synth.sample_table(2000, 4096, 4, 77)
+    p = api.default_pnp_params()
+    p.reproj_thr, p.confidence = thr, conf
+    g = ctx.pnp_ransac(pr["X"], pr["x"], pr["K"], pr["dist"], S, p)
+    o = oracle.pnp_ransac(pr["X"], pr["x"], pr["K"], pr["dist"], S, _pp(oracle, p))
+    assert g["rc"] == 0 and o["rc"] == 0
+    np.testing.assert_array_equal(g["counts"], o["counts"])
+    assert g["best_h"] == o["best_h"] and g["n_inliers"] == o["n_inliers"]
+    np.testing.assert_array_equal(g["inliers"], o["inliers"])
+    _close(g["Rt"], o["Rt"])
+    _close(g["rvec"], o["rvec"])
+    _close(g["tvec"], o["tvec"])
+    # and the pose is right: close to the ground truth, all true inliers found
+    assert np.abs(g["Rt"][:, :3] - pr["R"]).max() < 1e-3
+    assert g["inliers"][~pr["outlier"]].mean() > 0.97
+
+
+def test_pnp_small_and_degenerate(ctx, oracle):
+    pr = synth.pnp_problem(12, 5, noise=0.1, outlier_frac=0.0)
+    S = synth.sample_table(12, 64, 4, 3)
+    p = api.default_pnp_params()
+    p.reproj_thr = 3.0
+    g = ctx.pnp_ransac(pr["X"], pr["x"], pr["K"], pr["dist"], S, p)
+    o = oracle.pnp_ransac(pr["X"], pr["x"], pr["K"], pr["dist"], S, _pp(oracle, p))
+    np.testing.assert_array_equal(g["counts"], o["counts"])
+    _close(g["Rt"], o["Rt"])
+    with pytest.raises(api.MslamError) as e:
+        ctx.pnp_ransac(pr["X"][:3], pr["x"][:3], pr["K"], pr["dist"], S[:, :4] % 3, p)
+    assert e.value.status == api.ERR_TOO_FEW
+    # coincident world points: no P3P solution anywhere
+    X = np.zeros((10, 3)); X[:, 2] = 5.0
+    g = ctx.pnp_ransac(X, pr["x"][:10], pr["K"], pr["dist"], synth.sample_table(10, 8, 4, 1), p)
+    assert g["rc"] == api.ERR_DEGENERATE
+
+
+def test_pnp_batched_device(ctx, oracle):
+    B, P, H = 3, 500, 512
+    probs = [synth.pnp_problem(P, 100 + b) for b in range(B)]
+    S = np.stack([synth.sample_table(P, H, 4, 200 + b) for b in range(B)])
+    p = api.default_pnp_params()
+    p.reproj_thr = 2.0
+    D = api.DevBuf.from_array
+    dX, dx = D(ctx, np.stack([q["X"] for q in probs])), D(ctx, np.stack([q["x"] for q in probs]))
+    dK, dd = D(ctx, np.stack([q["K"] for q in probs])), D(ctx, np.stack([q["dist"] for q in probs]))
+    dS, dP = D(ctx, S), D(ctx, np.array([P, P - 7, P], np.int32))
+    Rt, inl = api.DevBuf(ctx, B * 96), api.DevBuf(ctx, B * P)
+    cnt, best, ninl = api.DevBuf(ctx, B * H * 4), api.DevBuf(ctx, B * 4), api.DevBuf(ctx, B * 4)
+    # ragged: problem 1 uses only its first P-7 points (samples are clamped into range on the host)
+    S1 = S.copy(); S1[1] %= (P - 7)
+    dS.upload(S1)
+    ctx.pnp_ransac_batch_dev(dX.ptr, dx.ptr, dP.ptr, P, dK.ptr, dd.ptr, dS.ptr, H, B, p, Rt.ptr, 0, 0, inl.ptr, cnt.ptr, best.ptr, ninl.ptr)
+    ctx.sync()
+    gRt, gc, gb = Rt.download(np.float64, (B, 3, 4)), cnt.download(np.int32, (B, H)), best.download(np.int32, (B,))
+    for b in range(B):
+        n = [P, P - 7, P][b]
+        o = oracle.pnp_ransac(probs[b]["X"][:n], probs[b]["x"][:n], probs[b]["K"], probs[b]["dist"], S1[b], _pp(oracle, p))
+        np.testing.assert_array_equal(gc[b], o["counts"])
+        assert gb[b] == o["best_h"]
+        _close(gRt[b], o["Rt"])
+
+
+def test_triangulate_matches_oracle(ctx, oracle):
+    tv = synth.two_view_problem(300, 9, outlier_frac=0.0)
+    Rt1 = np.eye(3, 4)
+    Rt2 = np.concatenate([tv["R"], tv["t"][:, None]], axis=1)
+    Xg, fg, ng = ctx.triangulate(tv["x1"], tv["x2"], Rt1, Rt2, tv["K"], tv["K"])
+    Xo, fo, no = oracle.triangulate(tv["x1"], tv["x2"], Rt1, Rt2, tv["K"], tv["K"])
+    np.testing.assert_array_equal(fg, fo)
+    assert ng == no == 300
+    np.testing.assert_allclose(Xg, Xo, rtol=1e-10, atol=1e-12)
+    # opposite baseline puts points behind a camera
+    Rt2b = np.concatenate([tv["R"], -tv["t"][:, None]], axis=1)
+    _, fg2, ng2 = ctx.triangulate(tv["x1"], tv["x2"], Rt1, Rt2b, tv["K"], tv["K"])
+    _, fo2, no2 = oracle.triangulate(tv["x1"], tv["x2"], Rt1, Rt2b, tv["K"], tv["K"])
+    np.testing.assert_array_equal(fg2, fo2)
+    assert ng2 == no2 and ng2 < 300
