@@ -218,6 +218,73 @@ class Context:
         self._check(rc, "mslam_match_knn2_batch_dev")
 
 
+def ba_problem_struct(pr: dict):
+    """dict (as synth.ba_problem) -> (mslam_ba_problem, keepalive arrays)"""
+    keep = dict(poses=np.ascontiguousarray(pr["poses"], np.float64), pose_fixed=np.ascontiguousarray(pr["pose_fixed"], np.uint8),
+                points=np.ascontiguousarray(pr["points"], np.float64), edge_pose=np.ascontiguousarray(pr["edge_pose"], np.int32),
+                edge_point=np.ascontiguousarray(pr["edge_point"], np.int32), obs=np.ascontiguousarray(pr["obs"], np.float64),
+                info=np.ascontiguousarray(pr["info"], np.float64), intr=np.ascontiguousarray(pr["intr"], np.float64))
+    s = BaProblem()
+    s.n_poses, s.n_points, s.n_edges = pr["n_poses"], pr["n_points"], pr["n_edges"]
+    s.poses = _p(keep["poses"], f64p); s.pose_fixed = _p(keep["pose_fixed"], u8p); s.points = _p(keep["points"], f64p)
+    s.edge_pose = _p(keep["edge_pose"], i32p); s.edge_point = _p(keep["edge_point"], i32p)
+    s.obs = _p(keep["obs"], f64p); s.info = _p(keep["info"], f64p); s.intr = _p(keep["intr"], f64p)
+    s.huber_delta = pr["huber_delta"]
+    return s, keep
+
+
+def ba_system_alloc(n_edges: int, n_points: int, nf: int, nnzb: int):
+    a = dict(err=np.zeros((n_edges, 2)), chi2=np.zeros(n_edges), rho1=np.zeros(n_edges), Hpp=np.zeros((nf, 6, 6)),
+             Hll=np.zeros((n_points, 3, 3)), Hpl_rowptr=np.zeros(nf + 1, np.int32), Hpl_col=np.zeros(max(nnzb, 1), np.int32),
+             Hpl_val=np.zeros((max(nnzb, 1), 6, 3)), b=np.zeros(6 * nf + 3 * n_points))
+    s = BaSystem()
+    for k in ("err", "chi2", "rho1", "Hpp", "Hll", "Hpl_val", "b"):
+        setattr(s, k, _p(a[k], f64p))
+    s.Hpl_rowptr = _p(a["Hpl_rowptr"], i32p); s.Hpl_col = _p(a["Hpl_col"], i32p)
+    return s, a
+
+
+class BaPlan:
+    """Device-resident BA structure + state for the LM loop (mslam_ba_plan_*)."""
+
+    def __init__(self, ctx: "Context", pr: dict):
+        self.ctx = ctx
+        self.pr = pr
+        ps, self._keep = ba_problem_struct(pr)
+        self._h = vp()
+        ctx._check(lib().mslam_ba_plan_create(ctx.handle, C.byref(ps), C.byref(self._h)), "mslam_ba_plan_create")
+        self.view = BaDevView()
+        ctx._check(lib().mslam_ba_plan_view(self._h, C.byref(self.view)), "mslam_ba_plan_view")
+
+    def set_state(self, poses=None, points=None):
+        a = np.ascontiguousarray(poses, np.float64) if poses is not None else None
+        b = np.ascontiguousarray(points, np.float64) if points is not None else None
+        self.ctx._check(lib().mslam_ba_plan_set_state(self._h, _p(a, f64p) if a is not None else None,
+                                                      _p(b, f64p) if b is not None else None), "mslam_ba_plan_set_state")
+
+    def build_dev(self):
+        self.ctx._check(lib().mslam_ba_plan_build_dev(self._h), "mslam_ba_plan_build_dev")
+
+    def download(self):
+        nf, nnzb = self.view.n_free_poses, self.view.nnzb
+        ss, a = ba_system_alloc(self.pr["n_edges"], self.pr["n_points"], nf, nnzb)
+        self.ctx._check(lib().mslam_ba_plan_download(self._h, C.byref(ss)), "mslam_ba_plan_download")
+        a["Hpl_col"] = a["Hpl_col"][:nnzb]; a["Hpl_val"] = a["Hpl_val"][:nnzb]
+        a.update(robust_chi2=ss.robust_chi2, n_free_poses=ss.n_free_poses, nnzb=ss.nnzb)
+        return a
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            lib().mslam_ba_plan_destroy(self._h)
+            self._h = vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def _ctx_methods():
     def fmat_ransac8(self, x1, x2, samples, params: FmatParams):
         """R8/R9: eight-point F-matrix RANSAC over an explicit H x 8 sample table."""
@@ -276,7 +343,18 @@ def _ctx_methods():
                                                      o(tvec_ptr), vp(inl_ptr), o(counts_ptr), vp(best_ptr), vp(ninl_ptr)),
                     "mslam_pnp_ransac_batch_dev")
 
-    for f in (fmat_ransac8, pnp_ransac, triangulate, fmat_ransac8_batch_dev, pnp_ransac_batch_dev):
+    def ba_build(self, pr: dict):
+        """R15-R17: one linearisation of the BA problem `pr` (dict as synth.ba_problem) -> dict of system blocks."""
+        ps, keep = ba_problem_struct(pr)
+        nf, nnzb = C.c_int(0), C.c_int(0)
+        self._check(lib().mslam_ba_sizes(C.byref(ps), C.byref(nf), C.byref(nnzb)), "mslam_ba_sizes")
+        ss, a = ba_system_alloc(pr["n_edges"], pr["n_points"], nf.value, nnzb.value)
+        self._check(lib().mslam_ba_build(self._h, C.byref(ps), C.byref(ss)), "mslam_ba_build")
+        a["Hpl_col"] = a["Hpl_col"][: nnzb.value]; a["Hpl_val"] = a["Hpl_val"][: nnzb.value]
+        a.update(robust_chi2=ss.robust_chi2, n_free_poses=ss.n_free_poses, nnzb=ss.nnzb)
+        return a
+
+    for f in (fmat_ransac8, pnp_ransac, triangulate, fmat_ransac8_batch_dev, pnp_ransac_batch_dev, ba_build):
         setattr(Context, f.__name__, f)
 
 

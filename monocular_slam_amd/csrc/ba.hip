@@ -1,0 +1,425 @@
+// ba.hip -- K9: bundle-adjustment linearisation on gfx950: reprojection residuals, Huber
+// weights, analytic 2x3 / 2x6 Jacobians and the J^T w Omega J blocks, written straight into the
+// block layout the host-side Schur / LDL^T solve consumes (Hpp, Hll, block-CSR Hpl, b).
+//
+// Stands in for one pass of BlockSolver<6,3>::buildSystem (reference ThirdParty/g2o/g2o/core/
+// block_solver.hpp:502-560) over the graph of Util::BundleAdjustment (src/Util.cpp:34-170):
+// EdgeSE3ProjectXYZ::computeError / linearizeOplus (types/types_six_dof_expmap.h:90-95,
+// types_six_dof_expmap.cpp:103-139), RobustKernelHuber::robustify (core/robust_kernel_impl.cpp:78-91),
+// BaseBinaryEdge::constructQuadraticForm (core/base_binary_edge.hpp:55-120).
+//
+// HBM layout (device-resident plan, built once per graph like g2o's buildStructure):
+//   state    poses f64[n_poses][7] (t, q xyzw), points f64[n_points][3]
+//   edges    edge_pose/edge_point i32[E], obs f64[E][2], info f64[E], intr f64[n_poses][4]
+//   by point pt_ptr i32[n_points+1], pt_edge i32[E]   (edges of a point, ascending edge id)
+//   Hpl      rowptr i32[fp+1], col i32[nnzb], val f64[nnzb][6][3] (row = free pose, col = point,
+//            sorted by point), blk_edge i32[nnzb] (edge of a block), slot i32[E] (block of an edge)
+// Kernels:
+//   ba_points_k  16 lanes per point: lane l takes the point's edges l, l+16, ...: residual, Huber
+//                weight, Jacobians, writes err/chi2/rho1 and the edge's 6x3 Hpl block, keeps the 3x3
+//                Hll / b_l contribution in registers; a fixed-order butterfly over the 16 lanes sums
+//                them (no float atomics: results are run-to-run identical)
+//   ba_poses_k   grid (free pose, chunk): one lane per Hpl block of the pose recomputes B and the
+//                weight (cheaper than re-reading 216 B per edge) and a fixed-tree block reduction
+//                produces the chunk's 6x6 (21 unique) + 6 sums
+//   ba_final_k   adds the chunk partials per pose in chunk order, reduces the robust chi2
+// f64 throughout (g2o is double; 1e-4 relative parity is an f64 target).  FMA contraction is
+// allowed in this file: no discrete decision depends on the last bit here.
+#include "common.h"
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#pragma clang fp contract(fast)
+
+namespace {
+
+constexpr int GROUP = 16;          // lanes per point
+constexpr int BA_THREADS = 256;
+constexpr int POSE_CHUNK = 256;    // Hpl blocks per pose-chunk workgroup
+
+struct BaDev {
+    int n_poses, n_points, n_edges, n_free, nnzb, n_chunks_max;
+    double huber_delta; float dsqr;
+    const double* poses; const double* points;
+    const int32_t* edge_pose; const int32_t* edge_point; const double* obs; const double* info; const double* intr;
+    const int32_t* fidx;      // free index per pose or -1
+    const int32_t* pt_ptr; const int32_t* pt_edge;
+    const int32_t* rowptr; const int32_t* blk_edge; const int32_t* slot;
+    double* err; double* chi2; double* rho1; double* Hpp; double* Hll; double* Hpl_val; double* b;
+    double* pt_rho;           // [n_points] robust chi2 per point
+    double* pose_part;        // [n_free][n_chunks_max][27]
+    double* robust_chi2;      // [1]
+};
+
+struct EdgeLin { double e0, e1, A[6], B[12]; };
+
+// computeError + linearizeOplus (Eigen's quaternion * vector and toRotationMatrix restated)
+__device__ __forceinline__ void edge_eval(const double* __restrict__ pose, double X0, double X1, double X2, double ox, double oy,
+                                          double fx, double fy, double cx, double cy, EdgeLin& L)
+{
+    const double tx_ = pose[0], ty_ = pose[1], tz_ = pose[2], qx = pose[3], qy = pose[4], qz = pose[5], qw = pose[6];
+    double ux = qy * X2 - qz * X1, uy = qz * X0 - qx * X2, uz = qx * X1 - qy * X0;
+    ux += ux; uy += uy; uz += uz;
+    const double x = X0 + qw * ux + (qy * uz - qz * uy) + tx_;
+    const double y = X1 + qw * uy + (qz * ux - qx * uz) + ty_;
+    const double z = X2 + qw * uz + (qx * uy - qy * ux) + tz_;
+    const double iz = 1.0 / z;
+    L.e0 = ox - (x * iz * fx + cx);
+    L.e1 = oy - (y * iz * fy + cy);
+    const double z_2 = z * z;
+    const double tx = 2 * qx, ty = 2 * qy, tz = 2 * qz;
+    const double twx = tx * qw, twy = ty * qw, twz = tz * qw, txx = tx * qx, txy = ty * qx, txz = tz * qx, tyy = ty * qy, tyz = tz * qy, tzz = tz * qz;
+    const double R[9] = { 1 - (tyy + tzz), txy - twz, txz + twy, txy + twz, 1 - (txx + tzz), tyz - twx, txz - twy, tyz + twx, 1 - (txx + tyy) };
+    const double s = -iz;
+    const double t00 = s * fx, t02 = s * (-x * iz * fx), t11 = s * fy, t12 = s * (-y * iz * fy);
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        L.A[j] = t00 * R[j] + t02 * R[6 + j];
+        L.A[3 + j] = t11 * R[3 + j] + t12 * R[6 + j];
+    }
+    L.B[0] = x * y / z_2 * fx;       L.B[1] = -(1 + (x * x / z_2)) * fx; L.B[2] = y * iz * fx;
+    L.B[3] = -iz * fx;               L.B[4] = 0;                         L.B[5] = x / z_2 * fx;
+    L.B[6] = (1 + y * y / z_2) * fy; L.B[7] = -x * y / z_2 * fy;         L.B[8] = -x * iz * fy;
+    L.B[9] = 0;                      L.B[10] = -iz * fy;                 L.B[11] = y / z_2 * fy;
+}
+
+__device__ __forceinline__ void huber(double chi2, double delta, float dsqr, double& rho0, double& rho1)
+{
+    rho0 = chi2; rho1 = 1.0;
+    if (delta > 0 && !(chi2 <= (double)dsqr)) {
+        const double sq = sqrt(chi2);
+        rho0 = 2 * sq * delta - (double)dsqr;
+        rho1 = delta / sq;
+    }
+}
+
+__global__ __launch_bounds__(BA_THREADS)
+void ba_points_k(BaDev d)
+{
+    const int gid = (blockIdx.x * BA_THREADS + threadIdx.x) / GROUP; // point
+    const int gl = threadIdx.x & (GROUP - 1);
+    const bool live = gid < d.n_points;
+    double acc[13]; // Hll upper (6): 00 01 02 11 12 22; b_l (3); rho (1); pad
+#pragma unroll
+    for (int k = 0; k < 13; k++) acc[k] = 0.0;
+    if (live) {
+        const double X0 = d.points[3 * gid], X1 = d.points[3 * gid + 1], X2 = d.points[3 * gid + 2];
+        const int e0 = d.pt_ptr[gid], e1 = d.pt_ptr[gid + 1];
+        for (int k = e0 + gl; k < e1; k += GROUP) {
+            const int e = d.pt_edge[k];
+            const int jp = d.edge_pose[e];
+            const double* in = d.intr + 4 * jp;
+            EdgeLin L;
+            edge_eval(d.poses + 7 * jp, X0, X1, X2, d.obs[2 * e], d.obs[2 * e + 1], in[0], in[1], in[2], in[3], L);
+            const double om = d.info[e];
+            const double chi2 = L.e0 * (om * L.e0) + L.e1 * (om * L.e1);
+            double rho0, rho1;
+            huber(chi2, d.huber_delta, d.dsqr, rho0, rho1);
+            d.err[2 * e] = L.e0; d.err[2 * e + 1] = L.e1; d.chi2[e] = chi2; d.rho1[e] = rho1;
+            const double wom = rho1 * om;
+            const double r0 = -(om * L.e0) * rho1, r1 = -(om * L.e1) * rho1;
+            const double* A = L.A;
+            acc[0] += wom * (A[0] * A[0] + A[3] * A[3]); acc[1] += wom * (A[0] * A[1] + A[3] * A[4]);
+            acc[2] += wom * (A[0] * A[2] + A[3] * A[5]); acc[3] += wom * (A[1] * A[1] + A[4] * A[4]);
+            acc[4] += wom * (A[1] * A[2] + A[4] * A[5]); acc[5] += wom * (A[2] * A[2] + A[5] * A[5]);
+            acc[6] += A[0] * r0 + A[3] * r1; acc[7] += A[1] * r0 + A[4] * r1; acc[8] += A[2] * r0 + A[5] * r1;
+            acc[9] += rho0;
+            const int sl = d.slot[e];
+            if (sl >= 0) { // B^T (w Omega) A, row-major 6x3
+                double* Hb = d.Hpl_val + (size_t)sl * 18;
+#pragma unroll
+                for (int a = 0; a < 6; a++) {
+                    const double ba = wom * L.B[a], bb = wom * L.B[6 + a];
+                    Hb[a * 3 + 0] = ba * A[0] + bb * A[3];
+                    Hb[a * 3 + 1] = ba * A[1] + bb * A[4];
+                    Hb[a * 3 + 2] = ba * A[2] + bb * A[5];
+                }
+            }
+        }
+    }
+    // fixed-order butterfly over the 16 lanes of the group
+#pragma unroll
+    for (int o = GROUP / 2; o > 0; o >>= 1)
+#pragma unroll
+        for (int k = 0; k < 10; k++) acc[k] += __shfl_xor(acc[k], o, GROUP);
+    if (live && gl == 0) {
+        double* H = d.Hll + (size_t)gid * 9;
+        H[0] = acc[0]; H[1] = acc[1]; H[2] = acc[2];
+        H[3] = acc[1]; H[4] = acc[3]; H[5] = acc[4];
+        H[6] = acc[2]; H[7] = acc[4]; H[8] = acc[5];
+        double* bl = d.b + 6 * d.n_free + 3 * (size_t)gid;
+        bl[0] = acc[6]; bl[1] = acc[7]; bl[2] = acc[8];
+        d.pt_rho[gid] = acc[9];
+    }
+}
+
+__global__ __launch_bounds__(POSE_CHUNK)
+void ba_poses_k(BaDev d)
+{
+    const int f = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
+    const int k0 = d.rowptr[f], k1 = d.rowptr[f + 1];
+    const int k = k0 + chunk * POSE_CHUNK + tid;
+    if (k0 + chunk * POSE_CHUNK >= k1) return; // whole block out of range
+    __shared__ double s_red[27 * POSE_CHUNK];
+    double v[27];
+#pragma unroll
+    for (int q = 0; q < 27; q++) v[q] = 0.0;
+    if (k < k1) {
+        const int e = d.blk_edge[k];
+        const int jp = d.edge_pose[e], ip = d.edge_point[e];
+        const double* in = d.intr + 4 * jp;
+        EdgeLin L;
+        edge_eval(d.poses + 7 * jp, d.points[3 * ip], d.points[3 * ip + 1], d.points[3 * ip + 2], d.obs[2 * e], d.obs[2 * e + 1],
+                  in[0], in[1], in[2], in[3], L);
+        const double om = d.info[e];
+        const double chi2 = L.e0 * (om * L.e0) + L.e1 * (om * L.e1);
+        double rho0, rho1;
+        huber(chi2, d.huber_delta, d.dsqr, rho0, rho1);
+        const double wom = rho1 * om;
+        const double r0 = -(om * L.e0) * rho1, r1 = -(om * L.e1) * rho1;
+        int q = 0;
+#pragma unroll
+        for (int a = 0; a < 6; a++)
+#pragma unroll
+            for (int c = a; c < 6; c++) v[q++] = wom * (L.B[a] * L.B[c] + L.B[6 + a] * L.B[6 + c]);
+#pragma unroll
+        for (int a = 0; a < 6; a++) v[21 + a] = L.B[a] * r0 + L.B[6 + a] * r1;
+    }
+#pragma unroll
+    for (int q = 0; q < 27; q++) s_red[q * POSE_CHUNK + tid] = v[q];
+    __syncthreads();
+    for (int o = POSE_CHUNK / 2; o > 0; o >>= 1) {
+        if (tid < o)
+#pragma unroll
+            for (int q = 0; q < 27; q++) s_red[q * POSE_CHUNK + tid] += s_red[q * POSE_CHUNK + tid + o];
+        __syncthreads();
+    }
+    if (tid < 27) d.pose_part[((size_t)f * d.n_chunks_max + chunk) * 27 + tid] = s_red[tid * POSE_CHUNK];
+}
+
+__global__ __launch_bounds__(256)
+void ba_final_k(BaDev d)
+{
+    const int tid = threadIdx.x;
+    // poses: one thread per (pose, value)
+    for (int i = tid; i < d.n_free * 27; i += 256) {
+        const int f = i / 27, q = i % 27;
+        const int nch = (d.rowptr[f + 1] - d.rowptr[f] + POSE_CHUNK - 1) / POSE_CHUNK;
+        double s = 0.0;
+        for (int c = 0; c < nch; c++) s += d.pose_part[((size_t)f * d.n_chunks_max + c) * 27 + q];
+        if (q < 21) {
+            int a = 0, rem = q; // unpack upper-triangle index
+            while (rem >= 6 - a) { rem -= 6 - a; a++; }
+            const int c2 = a + rem;
+            d.Hpp[(size_t)f * 36 + a * 6 + c2] = s;
+            d.Hpp[(size_t)f * 36 + c2 * 6 + a] = s;
+        } else d.b[6 * f + (q - 21)] = s;
+    }
+    // robust chi2: fixed-order tree over points
+    __shared__ double s_r[256];
+    double r = 0.0;
+    for (int i = tid; i < d.n_points; i += 256) r += d.pt_rho[i];
+    s_r[tid] = r;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (tid < o) s_r[tid] += s_r[tid + o]; __syncthreads(); }
+    if (tid == 0) d.robust_chi2[0] = s_r[0];
+}
+
+} // namespace
+
+struct mslam_ba_plan {
+    mslam_ctx* ctx = nullptr;
+    void* arena = nullptr;
+    BaDev dev{};
+    double* d_poses = nullptr; double* d_points = nullptr;
+    int32_t* d_rowptr = nullptr; int32_t* d_col = nullptr;
+    std::vector<int32_t> h_rowptr, h_col;
+};
+
+static int ba_validate(const mslam_ba_problem* p)
+{
+    if (!p || p->n_poses < 1 || p->n_points < 1 || p->n_edges < 1 || !p->poses || !p->pose_fixed || !p->points || !p->edge_pose ||
+        !p->edge_point || !p->obs || !p->info || !p->intr)
+        return MSLAM_ERR_INVALID;
+    for (int e = 0; e < p->n_edges; e++)
+        if (p->edge_pose[e] < 0 || p->edge_pose[e] >= p->n_poses || p->edge_point[e] < 0 || p->edge_point[e] >= p->n_points)
+            return MSLAM_ERR_INVALID;
+    return MSLAM_OK;
+}
+
+extern "C" {
+
+int mslam_ba_sizes(const mslam_ba_problem* p, int* n_free_poses, int* nnzb)
+{
+    MSLAM_TRY(ba_validate(p));
+    int nf = 0, nz = 0;
+    for (int j = 0; j < p->n_poses; j++) nf += !p->pose_fixed[j];
+    for (int e = 0; e < p->n_edges; e++) nz += !p->pose_fixed[p->edge_pose[e]];
+    if (n_free_poses) *n_free_poses = nf;
+    if (nnzb) *nnzb = nz;
+    return MSLAM_OK;
+}
+
+// structure analysis on the host (g2o: SparseOptimizer::buildIndexMapping + BlockSolver::buildStructure)
+int mslam_ba_plan_create(mslam_ctx* ctx, const mslam_ba_problem* p, mslam_ba_plan** out)
+{
+    if (!ctx || !out) return MSLAM_ERR_INVALID;
+    MSLAM_TRY(ba_validate(p));
+    MSLAM_TRY(ctx_set_device(ctx));
+    const int NP = p->n_poses, NL = p->n_points, E = p->n_edges;
+    std::vector<int32_t> fidx(NP), pt_ptr(NL + 1, 0), pt_edge(E), slot(E, -1);
+    int nf = 0;
+    for (int j = 0; j < NP; j++) fidx[j] = p->pose_fixed[j] ? -1 : nf++;
+    for (int e = 0; e < E; e++) pt_ptr[p->edge_point[e] + 1]++;
+    for (int i = 0; i < NL; i++) pt_ptr[i + 1] += pt_ptr[i];
+    {
+        std::vector<int32_t> fill(NL, 0);
+        for (int e = 0; e < E; e++) { int i = p->edge_point[e]; pt_edge[pt_ptr[i] + fill[i]++] = e; } // ascending edge id
+    }
+    std::vector<int32_t> rowptr(nf + 1, 0);
+    for (int e = 0; e < E; e++) { int f = fidx[p->edge_pose[e]]; if (f >= 0) rowptr[f + 1]++; }
+    for (int f = 0; f < nf; f++) rowptr[f + 1] += rowptr[f];
+    const int nnzb = rowptr[nf];
+    std::vector<std::pair<int32_t, int32_t>> pe(nnzb);
+    {
+        std::vector<int32_t> fill(nf, 0);
+        for (int e = 0; e < E; e++) { int f = fidx[p->edge_pose[e]]; if (f >= 0) pe[rowptr[f] + fill[f]++] = { p->edge_point[e], e }; }
+    }
+    int max_row = 0;
+    for (int f = 0; f < nf; f++) {
+        std::sort(pe.begin() + rowptr[f], pe.begin() + rowptr[f + 1]);
+        max_row = std::max(max_row, rowptr[f + 1] - rowptr[f]);
+    }
+    std::vector<int32_t> col(nnzb), blk_edge(nnzb);
+    for (int k = 0; k < nnzb; k++) { col[k] = pe[k].first; blk_edge[k] = pe[k].second; slot[pe[k].second] = k; }
+    const int n_chunks_max = std::max(1, (max_row + POSE_CHUNK - 1) / POSE_CHUNK);
+
+    mslam_ba_plan* pl = new mslam_ba_plan();
+    pl->ctx = ctx;
+    size_t bytes = 0;
+    auto reserve = [&](size_t n) { bytes = align_up(bytes, 256); size_t o = bytes; bytes += n; return o; };
+    const size_t o_poses = reserve(sizeof(double) * 7 * NP), o_points = reserve(sizeof(double) * 3 * NL),
+                 o_ep = reserve(sizeof(int32_t) * E), o_el = reserve(sizeof(int32_t) * E), o_obs = reserve(sizeof(double) * 2 * E),
+                 o_info = reserve(sizeof(double) * E), o_intr = reserve(sizeof(double) * 4 * NP), o_fidx = reserve(sizeof(int32_t) * NP),
+                 o_ptp = reserve(sizeof(int32_t) * (NL + 1)), o_pte = reserve(sizeof(int32_t) * E),
+                 o_row = reserve(sizeof(int32_t) * (nf + 1)), o_col = reserve(sizeof(int32_t) * std::max(nnzb, 1)),
+                 o_be = reserve(sizeof(int32_t) * std::max(nnzb, 1)), o_slot = reserve(sizeof(int32_t) * E),
+                 o_err = reserve(sizeof(double) * 2 * E), o_chi = reserve(sizeof(double) * E), o_rho = reserve(sizeof(double) * E),
+                 o_hpp = reserve(sizeof(double) * 36 * std::max(nf, 1)), o_hll = reserve(sizeof(double) * 9 * NL),
+                 o_hpl = reserve(sizeof(double) * 18 * std::max(nnzb, 1)), o_b = reserve(sizeof(double) * (6 * nf + 3 * NL)),
+                 o_ptr = reserve(sizeof(double) * NL), o_pp = reserve(sizeof(double) * 27 * (size_t)std::max(nf, 1) * n_chunks_max),
+                 o_rc = reserve(sizeof(double));
+    hipError_t he = hipMalloc(&pl->arena, bytes);
+    if (he != hipSuccess) { ctx->last_hip_error = std::string("hipMalloc(ba plan): ") + hipGetErrorString(he); delete pl; return MSLAM_ERR_HIP; }
+    char* base = (char*)pl->arena;
+    hipStream_t st = ctx->stream;
+    auto up = [&](size_t off, const void* src, size_t n) { return n ? hipMemcpyAsync(base + off, src, n, hipMemcpyHostToDevice, st) : hipSuccess; };
+    hipError_t errs[] = {
+        up(o_poses, p->poses, sizeof(double) * 7 * NP), up(o_points, p->points, sizeof(double) * 3 * NL),
+        up(o_ep, p->edge_pose, sizeof(int32_t) * E), up(o_el, p->edge_point, sizeof(int32_t) * E),
+        up(o_obs, p->obs, sizeof(double) * 2 * E), up(o_info, p->info, sizeof(double) * E), up(o_intr, p->intr, sizeof(double) * 4 * NP),
+        up(o_fidx, fidx.data(), sizeof(int32_t) * NP), up(o_ptp, pt_ptr.data(), sizeof(int32_t) * (NL + 1)),
+        up(o_pte, pt_edge.data(), sizeof(int32_t) * E), up(o_row, rowptr.data(), sizeof(int32_t) * (nf + 1)),
+        up(o_col, col.data(), sizeof(int32_t) * nnzb), up(o_be, blk_edge.data(), sizeof(int32_t) * nnzb),
+        up(o_slot, slot.data(), sizeof(int32_t) * E), hipStreamSynchronize(st) };
+    for (hipError_t e : errs)
+        if (e != hipSuccess) { ctx->last_hip_error = std::string("ba plan upload: ") + hipGetErrorString(e); (void)hipFree(pl->arena); delete pl; return MSLAM_ERR_HIP; }
+    BaDev& d = pl->dev;
+    d.n_poses = NP; d.n_points = NL; d.n_edges = E; d.n_free = nf; d.nnzb = nnzb; d.n_chunks_max = n_chunks_max;
+    d.huber_delta = p->huber_delta; d.dsqr = (float)(p->huber_delta * p->huber_delta); // RobustKernelHuber: float dsqr
+    d.poses = (double*)(base + o_poses); d.points = (double*)(base + o_points);
+    d.edge_pose = (int32_t*)(base + o_ep); d.edge_point = (int32_t*)(base + o_el); d.obs = (double*)(base + o_obs);
+    d.info = (double*)(base + o_info); d.intr = (double*)(base + o_intr); d.fidx = (int32_t*)(base + o_fidx);
+    d.pt_ptr = (int32_t*)(base + o_ptp); d.pt_edge = (int32_t*)(base + o_pte);
+    d.rowptr = (int32_t*)(base + o_row); d.blk_edge = (int32_t*)(base + o_be); d.slot = (int32_t*)(base + o_slot);
+    d.err = (double*)(base + o_err); d.chi2 = (double*)(base + o_chi); d.rho1 = (double*)(base + o_rho);
+    d.Hpp = (double*)(base + o_hpp); d.Hll = (double*)(base + o_hll); d.Hpl_val = (double*)(base + o_hpl); d.b = (double*)(base + o_b);
+    d.pt_rho = (double*)(base + o_ptr); d.pose_part = (double*)(base + o_pp); d.robust_chi2 = (double*)(base + o_rc);
+    pl->d_poses = (double*)(base + o_poses); pl->d_points = (double*)(base + o_points);
+    pl->d_rowptr = (int32_t*)(base + o_row); pl->d_col = (int32_t*)(base + o_col);
+    pl->h_rowptr = rowptr; pl->h_col = col;
+    *out = pl;
+    return MSLAM_OK;
+}
+
+void mslam_ba_plan_destroy(mslam_ba_plan* pl)
+{
+    if (!pl) return;
+    (void)hipSetDevice(pl->ctx->device);
+    (void)hipStreamSynchronize(pl->ctx->stream);
+    if (pl->arena) (void)hipFree(pl->arena);
+    delete pl;
+}
+
+int mslam_ba_plan_view(mslam_ba_plan* pl, mslam_ba_dev_view* v)
+{
+    if (!pl || !v) return MSLAM_ERR_INVALID;
+    const BaDev& d = pl->dev;
+    v->poses = pl->d_poses; v->points = pl->d_points; v->err = d.err; v->chi2 = d.chi2; v->rho1 = d.rho1;
+    v->Hpp = d.Hpp; v->Hll = d.Hll; v->Hpl_val = d.Hpl_val; v->b = d.b; v->Hpl_rowptr = pl->d_rowptr; v->Hpl_col = pl->d_col;
+    v->robust_chi2 = d.robust_chi2; v->n_free_poses = d.n_free; v->nnzb = d.nnzb;
+    return MSLAM_OK;
+}
+
+int mslam_ba_plan_set_state(mslam_ba_plan* pl, const double* poses, const double* points)
+{
+    if (!pl) return MSLAM_ERR_INVALID;
+    mslam_ctx* ctx = pl->ctx;
+    MSLAM_TRY(ctx_set_device(ctx));
+    if (poses) HIP_TRY(ctx, hipMemcpyAsync(pl->d_poses, poses, sizeof(double) * 7 * pl->dev.n_poses, hipMemcpyHostToDevice, ctx->stream));
+    if (points) HIP_TRY(ctx, hipMemcpyAsync(pl->d_points, points, sizeof(double) * 3 * pl->dev.n_points, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return MSLAM_OK;
+}
+
+int mslam_ba_plan_build_dev(mslam_ba_plan* pl)
+{
+    if (!pl) return MSLAM_ERR_INVALID;
+    mslam_ctx* ctx = pl->ctx;
+    const BaDev& d = pl->dev;
+    hipStream_t st = ctx->stream;
+    const int groups_per_block = BA_THREADS / GROUP;
+    hipLaunchKernelGGL(ba_points_k, dim3((d.n_points + groups_per_block - 1) / groups_per_block), dim3(BA_THREADS), 0, st, d);
+    if (d.n_free > 0 && d.nnzb > 0)
+        hipLaunchKernelGGL(ba_poses_k, dim3(d.n_chunks_max, d.n_free), dim3(POSE_CHUNK), 0, st, d);
+    hipLaunchKernelGGL(ba_final_k, dim3(1), dim3(256), 0, st, d);
+    HIP_TRY(ctx, hipGetLastError());
+    return MSLAM_OK;
+}
+
+int mslam_ba_plan_download(mslam_ba_plan* pl, mslam_ba_system* s)
+{
+    if (!pl || !s) return MSLAM_ERR_INVALID;
+    mslam_ctx* ctx = pl->ctx;
+    const BaDev& d = pl->dev;
+    hipStream_t st = ctx->stream;
+    auto dn = [&](void* dst, const void* src, size_t n) { return (dst && n) ? hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, st) : hipSuccess; };
+    HIP_TRY(ctx, dn(s->err, d.err, sizeof(double) * 2 * d.n_edges));
+    HIP_TRY(ctx, dn(s->chi2, d.chi2, sizeof(double) * d.n_edges));
+    HIP_TRY(ctx, dn(s->rho1, d.rho1, sizeof(double) * d.n_edges));
+    HIP_TRY(ctx, dn(s->Hpp, d.Hpp, sizeof(double) * 36 * d.n_free));
+    HIP_TRY(ctx, dn(s->Hll, d.Hll, sizeof(double) * 9 * d.n_points));
+    HIP_TRY(ctx, dn(s->Hpl_val, d.Hpl_val, sizeof(double) * 18 * d.nnzb));
+    HIP_TRY(ctx, dn(s->b, d.b, sizeof(double) * (6 * d.n_free + 3 * d.n_points)));
+    HIP_TRY(ctx, dn(&s->robust_chi2, d.robust_chi2, sizeof(double)));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    if (s->Hpl_rowptr) std::memcpy(s->Hpl_rowptr, pl->h_rowptr.data(), sizeof(int32_t) * (d.n_free + 1));
+    if (s->Hpl_col && d.nnzb) std::memcpy(s->Hpl_col, pl->h_col.data(), sizeof(int32_t) * d.nnzb);
+    s->n_free_poses = d.n_free; s->nnzb = d.nnzb;
+    return MSLAM_OK;
+}
+
+int mslam_ba_build(mslam_ctx* ctx, const mslam_ba_problem* p, mslam_ba_system* s)
+{
+    if (!ctx || !s) return MSLAM_ERR_INVALID;
+    mslam_ba_plan* pl = nullptr;
+    MSLAM_TRY(mslam_ba_plan_create(ctx, p, &pl));
+    int rc = mslam_ba_plan_build_dev(pl);
+    if (rc == MSLAM_OK) rc = mslam_ba_plan_download(pl, s);
+    mslam_ba_plan_destroy(pl);
+    return rc;
+}
+
+} // extern "C"

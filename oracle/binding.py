@@ -199,3 +199,52 @@ def pose_from_F(F, K1, K2, x1, x2):
     best = lib().orc_pose_from_F(_p(a[0], f64p), _p(a[1], f64p), _p(a[2], f64p), _p(x1, f64p), _p(x2, f64p), n,
                                  _p(Rt, f64p), _p(X, f64p), _p(counts, i32p))
     return best, Rt.reshape(3, 4), X, counts
+
+
+def _ba_problem_struct(pr, cls=None):
+    """pr: dict from synth.ba_problem -> (struct, keepalive list)"""
+    cls = cls or BaProblem
+    keep = dict(poses=np.ascontiguousarray(pr["poses"], np.float64), pose_fixed=np.ascontiguousarray(pr["pose_fixed"], np.uint8),
+                points=np.ascontiguousarray(pr["points"], np.float64), edge_pose=np.ascontiguousarray(pr["edge_pose"], np.int32),
+                edge_point=np.ascontiguousarray(pr["edge_point"], np.int32), obs=np.ascontiguousarray(pr["obs"], np.float64),
+                info=np.ascontiguousarray(pr["info"], np.float64), intr=np.ascontiguousarray(pr["intr"], np.float64))
+    s = cls()
+    s.n_poses, s.n_points, s.n_edges = pr["n_poses"], pr["n_points"], pr["n_edges"]
+    s.poses = _p(keep["poses"], f64p); s.pose_fixed = _p(keep["pose_fixed"], u8p); s.points = _p(keep["points"], f64p)
+    s.edge_pose = _p(keep["edge_pose"], i32p); s.edge_point = _p(keep["edge_point"], i32p)
+    s.obs = _p(keep["obs"], f64p); s.info = _p(keep["info"], f64p); s.intr = _p(keep["intr"], f64p)
+    s.huber_delta = pr["huber_delta"]
+    return s, keep
+
+
+def _ba_system_alloc(n_edges, n_points, nf, nnzb, cls=None):
+    cls = cls or BaSystem
+    a = dict(err=np.zeros((n_edges, 2)), chi2=np.zeros(n_edges), rho1=np.zeros(n_edges), Hpp=np.zeros((nf, 6, 6)),
+             Hll=np.zeros((n_points, 3, 3)), Hpl_rowptr=np.zeros(nf + 1, np.int32), Hpl_col=np.zeros(max(nnzb, 1), np.int32),
+             Hpl_val=np.zeros((max(nnzb, 1), 6, 3)), b=np.zeros(6 * nf + 3 * n_points))
+    s = cls()
+    for k in ("err", "chi2", "rho1", "Hpp", "Hll", "Hpl_val", "b"):
+        setattr(s, k, _p(a[k], f64p))
+    s.Hpl_rowptr = _p(a["Hpl_rowptr"], i32p); s.Hpl_col = _p(a["Hpl_col"], i32p)
+    return s, a
+
+
+def ba_build(pr):
+    ps, keep = _ba_problem_struct(pr)
+    nf, nnzb = C.c_int(0), C.c_int(0)
+    lib().orc_ba_sizes(C.byref(ps), C.byref(nf), C.byref(nnzb))
+    ss, a = _ba_system_alloc(pr["n_edges"], pr["n_points"], nf.value, nnzb.value)
+    rc = lib().orc_ba_build(C.byref(ps), C.byref(ss))
+    assert rc == 0
+    a["Hpl_col"] = a["Hpl_col"][: nnzb.value]; a["Hpl_val"] = a["Hpl_val"][: nnzb.value]
+    a.update(robust_chi2=ss.robust_chi2, n_free_poses=ss.n_free_poses, nnzb=ss.nnzb)
+    return a
+
+
+def ba_optimize(pr, iterations: int):
+    ps, keep = _ba_problem_struct(pr)
+    poses = keep["poses"].copy(); points = keep["points"].copy()
+    hist = np.zeros(iterations + 1); nh = C.c_int(0)
+    lib().orc_ba_optimize.restype = C.c_int
+    done = lib().orc_ba_optimize(C.byref(ps), _p(poses, f64p), _p(points, f64p), iterations, _p(hist, f64p), C.byref(nh))
+    return dict(poses=poses, points=points, chi2=hist[: nh.value].copy(), iterations=done)
