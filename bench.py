@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""Benchmark of the tracking hot path on MI355X: frames/sec of (ORB extract + Hamming match + PnP RANSAC)
+at 1920x1080, 2000 keypoints/frame (BASELINE.json metric), one process per GPU.
+
+  python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+
+A step is one pass of the hot path over one batch of B independent streams per GPU, frames resident in
+HBM: K1-K6 extract (1080p, nfeatures 2000), K7 kNN-2 + ratio test against the previous frame of the same
+stream, K8b PnP RANSAC on a synthetic 2000-correspondence / 4096-hypothesis / 2 px problem per frame
+(BASELINE configs[1] + configs[2]).  Streams are independent, so ranks share nothing: weak scaling, no
+data-path collective; torch.distributed is used only for the barrier and the
+max-over-ranks time.  The timed region holds only C-ABI calls into libmslam_hip.so (no CPU fallback
+exists); the oracle is loaded only for the separately reported cpu_baseline.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+W, H, NFEAT = 1920, 1080, 2000
+PNP_P, PNP_H, PNP_THR = 2000, 4096, 2.0
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+
+# algorithmic bytes per unit: extract W*H + 56*N; match 32*(Nq+Nt) + 16*Nq;
+# PnP 40*P + 4*s*H + 48 + P + 4*H
+ALG_BYTES = {
+    "extract": W * H + 56 * NFEAT,
+    "match": 32 * (NFEAT + NFEAT) + 16 * NFEAT,
+    "pnp": 40 * PNP_P + 4 * 4 * PNP_H + 48 + PNP_P + 4 * PNP_H,
+}
+KERNEL_UNIT = {  # which per-frame unit a kernel's launch is priced against
+    "bgr2gray_k": "extract", "resize_k": "extract", "fast_nms_k": "extract", "select_k": "extract", "describe_k": "extract",
+    "hamming_knn2_partial": "match", "knn2_finalize": "match",
+    "pnp_prepare_k": "pnp", "pnp_solve_k": "pnp", "pnp_score_k": "pnp", "ransac_select_k": "pnp", "pnp_finalize_k": "pnp",
+}
+
+
+def make_frames(B: int, seed0: int) -> np.ndarray:
+    from monocular_slam_amd import synth
+    nbase = min(B, 4)
+    base = [synth.textured_frame(W, H, seed0 + i) for i in range(nbase)]
+    return np.stack([synth.shifted_frame(base[i % nbase], 3 * (i // nbase), 2 * (i // nbase), seed0 + 100 + i) for i in range(B)])
+
+
+def make_pnp(B: int, seed0: int):
+    from monocular_slam_amd import synth
+    probs = [synth.pnp_problem(PNP_P, seed0 + b) for b in range(B)]
+    base = synth.sample_table(PNP_P, PNP_H, 4, seed0)
+    samples = np.stack([(base + 7 * b) % PNP_P for b in range(B)]).astype(np.int32)  # distinct indices stay distinct
+    return (np.stack([q["X"] for q in probs]), np.stack([q["x"] for q in probs]), np.stack([q["K"] for q in probs]),
+            np.stack([q["dist"] for q in probs]), samples, probs)
+
+
+def cpu_baseline(frames: np.ndarray, pnp, n_frames: int) -> dict:
+    """The oracle (CPU restatement) on this host's cores, single thread like the reference (src/Pipeline.h:57-64)."""
+    from oracle import binding as ob
+    ob.build()
+    X, x, K, dist, samples, _ = pnp
+    p = ob.orb_default_params(NFEAT)
+    pp = ob.pnp_default_params()
+    pp.reproj_thr = PNP_THR
+    B = frames.shape[0]
+    prev = None
+    t0 = time.perf_counter()
+    done = 0
+    for i in range(n_frames + 1):
+        b = i % B
+        kps, desc = ob.orb_extract(frames[b], p, cap=8192)
+        if prev is not None:
+            rc, idx, dist_ = ob.match_knn2(desc, prev)
+            ob.ratio_filter(idx, dist_, 0.8)
+            ob.pnp_ransac(X[b], x[b], K[b], dist[b], samples[b], pp)
+            done += 1
+        else:
+            t0 = time.perf_counter()  # the first frame only primes `prev`
+        prev = desc
+    dt = time.perf_counter() - t0
+    return {"value": done / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": f"{done} frames of the same workload (1920x1080 extract 2000 kpts + 2000x2000 match + PnP 2000x4096), "
+                      f"oracle/liboracle.so single thread, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="independent streams per GPU per step")
+    ap.add_argument("--cpu-frames", type=int, default=24, help="frames of the cpu_baseline sample (0 = skip)")
+    ap.add_argument("--no-kernel-events", action="store_true", help="skip the second, event-instrumented pass")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+        args.gpus = world
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from monocular_slam_amd import api
+    from monocular_slam_amd.tracking import TrackingBatch
+
+    B = args.batch
+    ctx = api.Context(local_rank, W, H, 4096, B)
+    tb = TrackingBatch(ctx, B, W, H, NFEAT, cap=NFEAT + 1024, ratio=0.8, pnp_points=PNP_P, pnp_hyps=PNP_H)
+    frames = make_frames(B, 5005 + 1000 * rank)
+    tb.upload_frames(frames)
+    pnp = make_pnp(B, 3003 + 1000 * rank)
+    pp = api.default_pnp_params()
+    pp.reproj_thr = PNP_THR
+    tb.set_pnp_problems(*pnp[:5], pp)
+
+    def barrier():
+        ctx.sync()
+        if dist is not None:
+            import torch
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        tb.step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        tb.step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    res = tb.results()
+    ok = bool((res["status"] == 0).all() and (res["n"] > NFEAT // 2).all() and (res["ninl"] > PNP_P // 2).all())
+
+    # second pass (rank 0 reports): the same steps with every launch bracketed by HIP events on the
+    # context's stream -> per-kernel average duration for the roofline of the dominant kernel
+    kern = {}
+    if not args.no_kernel_events:
+        ctx.profile_enable(64 * args.steps)
+        for _ in range(args.steps):
+            tb.step()
+        kern = ctx.profile_read()
+        ctx.profile_enable(0)
+
+    if rank == 0:
+        frames_total = world * B * args.steps
+        value = frames_total / elapsed
+        out = {
+            "metric": "frames/sec (extract+match+PnP) at 1920x1080, 2k kpts/frame", "value": value, "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/i32 (extract, match) + f64 (PnP)",
+            "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]+[2]: 1920x1080 gray frames, ORB nfeatures 2000 (8 levels, 1.2), "
+                                   "kNN-2 Hamming + ratio 0.8 vs previous frame, PnP RANSAC 2000 pts x 4096 hyps @ 2 px",
+                       "streams_per_gpu": B, "parallelism": f"{world} x independent streams (no collective)"},
+            "valid_outputs": ok,
+        }
+        if kern:
+            per = {k: v[0] / max(1, v[1]) for k, v in kern.items()}          # avg ms per launch
+            tot = {k: v[0] for k, v in kern.items()}
+            dom = max(tot, key=tot.get)
+            unit = KERNEL_UNIT.get(dom, "extract")
+            launches_per_step = kern[dom][1] / args.steps
+            alg = ALG_BYTES[unit] * B / launches_per_step                      # algorithmic bytes per launch
+            achieved = alg / (per[dom] * 1e-3) / 1e9
+            traffic = None
+            pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+            if os.path.exists(pmc_path):
+                try:
+                    traffic = json.load(open(pmc_path)).get(dom, {}).get("hbm_bytes_per_launch")
+                except Exception:
+                    traffic = None
+            out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                               "algorithmic_bytes_per_launch": alg, "avg_launch_ms": per[dom],
+                               "note": "algorithmic bytes (SURVEY 8d) of the %s unit x %d frames / launches per step; "
+                                       "the kernel is VALU/LDS-bound, not HBM-bound (DESIGN.md)" % (unit, B)}
+            out["kernel_ms_per_step"] = {k: v[0] / args.steps for k, v in sorted(kern.items(), key=lambda kv: -kv[1][0])}
+        if args.cpu_frames > 0 and world == 1:
+            out["cpu_baseline"] = cpu_baseline(frames, pnp, args.cpu_frames)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

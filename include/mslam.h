@@ -72,6 +72,14 @@ int mslam_event_destroy(mslam_ctx* ctx, void* ev);
 int mslam_event_record(mslam_ctx* ctx, void* ev);
 int mslam_event_elapsed_ms(mslam_ctx* ctx, void* ev_start, void* ev_stop, float* ms); /* syncs on stop */
 
+/* Per-kernel timing: when enabled, every kernel launch on this context is bracketed by HIP events
+ * on the context's stream (up to max_launches launches; 0 disables).  mslam_profile_read returns the
+ * summed milliseconds and the launch count per kernel id (arrays of mslam_profile_kernel_count()). */
+int mslam_profile_enable(mslam_ctx* ctx, int max_launches);
+int mslam_profile_kernel_count(void);
+const char* mslam_profile_kernel_name(int kid);
+int mslam_profile_read(mslam_ctx* ctx, double* total_ms, int32_t* launches);
+
 /* ---- R1-R6: ORB detect + describe --------------------------------------------------
  * Stands in for `detector.detect(frameBuffer, keypoints)` + `extractor.compute(
  * frameBuffer, keypoints, descriptor)` of FeatureExtractor::process

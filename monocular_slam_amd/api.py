@@ -168,6 +168,18 @@ class Context:
         self._check(lib().mslam_event_elapsed_ms(self._h, a, b, C.byref(ms)), "mslam_event_elapsed_ms")
         return float(ms.value)
 
+    # ---- per-kernel HIP-event timing
+    def profile_enable(self, max_launches: int):
+        self._check(lib().mslam_profile_enable(self._h, max_launches), "mslam_profile_enable")
+
+    def profile_read(self) -> dict:
+        """{kernel name: (total ms, launches)} since profile_enable (syncs)."""
+        n = lib().mslam_profile_kernel_count()
+        ms = np.zeros(n, np.float64); cnt = np.zeros(n, np.int32)
+        self._check(lib().mslam_profile_read(self._h, _p(ms, f64p), _p(cnt, i32p)), "mslam_profile_read")
+        lib().mslam_profile_kernel_name.restype = C.c_char_p
+        return {lib().mslam_profile_kernel_name(i).decode(): (float(ms[i]), int(cnt[i])) for i in range(n) if cnt[i] > 0}
+
     # ---- R1-R6
     def orb_extract(self, img: np.ndarray, params: OrbParams, cap: int | None = None):
         img = np.ascontiguousarray(img, dtype=np.uint8)

@@ -381,10 +381,10 @@ int mslam_ba_plan_build_dev(mslam_ba_plan* pl)
     const BaDev& d = pl->dev;
     hipStream_t st = ctx->stream;
     const int groups_per_block = BA_THREADS / GROUP;
-    hipLaunchKernelGGL(ba_points_k, dim3((d.n_points + groups_per_block - 1) / groups_per_block), dim3(BA_THREADS), 0, st, d);
+    LAUNCH(ctx, K_BA_POINTS, ba_points_k, dim3((d.n_points + groups_per_block - 1) / groups_per_block), dim3(BA_THREADS), 0, d);
     if (d.n_free > 0 && d.nnzb > 0)
-        hipLaunchKernelGGL(ba_poses_k, dim3(d.n_chunks_max, d.n_free), dim3(POSE_CHUNK), 0, st, d);
-    hipLaunchKernelGGL(ba_final_k, dim3(1), dim3(256), 0, st, d);
+        LAUNCH(ctx, K_BA_POSES, ba_poses_k, dim3(d.n_chunks_max, d.n_free), dim3(POSE_CHUNK), 0, d);
+    LAUNCH(ctx, K_BA_FINAL, ba_final_k, dim3(1), dim3(256), 0, d);
     HIP_TRY(ctx, hipGetLastError());
     return MSLAM_OK;
 }

@@ -9,7 +9,22 @@
 #define MSLAM_ABI_VERSION 1000
 
 struct OrbPlan;   // orb.hip
-struct MatchScratch;
+
+// kernel ids for the optional per-kernel HIP-event timing (mslam_profile_*)
+enum KernelId {
+    K_GRAY = 0, K_RESIZE, K_FAST_NMS, K_SELECT, K_DESCRIBE, K_MATCH_PARTIAL, K_MATCH_FINALIZE,
+    K_FMAT_PREPARE, K_FMAT_SOLVE, K_FMAT_SCORE, K_FMAT_FINALIZE, K_RANSAC_SELECT,
+    K_PNP_PREPARE, K_PNP_SOLVE, K_PNP_SCORE, K_PNP_FINALIZE, K_TRIANGULATE,
+    K_BA_POINTS, K_BA_POSES, K_BA_FINAL, K_COUNT
+};
+extern const char* const kKernelNames[K_COUNT];
+
+struct Prof {
+    bool on = false;
+    std::vector<hipEvent_t> ev;   // pairs: 2*i start, 2*i+1 stop
+    std::vector<int> kid;         // kernel id of pair i
+    size_t used = 0;
+};
 
 struct mslam_ctx {
     int device = -1;
@@ -23,7 +38,20 @@ struct mslam_ctx {
     // second arena for the host-pointer convenience wrappers (staging of inputs/outputs)
     void* stage = nullptr;
     size_t stage_bytes = 0;
+    Prof prof;
 };
+
+// returns the pair index or -1 (profiling off / pool exhausted)
+int prof_begin(mslam_ctx* ctx, int kid);
+void prof_end(mslam_ctx* ctx, int pair);
+
+// launch on the context's stream, bracketed by HIP events when profiling is enabled
+#define LAUNCH(ctx, KID, kernel, grid, block, shmem, ...)                                    \
+    do {                                                                                     \
+        int _pp = prof_begin((ctx), (KID));                                                  \
+        hipLaunchKernelGGL(kernel, grid, block, shmem, (ctx)->stream, __VA_ARGS__);          \
+        prof_end((ctx), _pp);                                                                \
+    } while (0)
 
 // record + return on HIP failure
 #define HIP_TRY(ctx, expr)                                                         \

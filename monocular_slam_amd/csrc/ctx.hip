@@ -2,6 +2,27 @@
 #include "common.h"
 #include <cstring>
 
+const char* const kKernelNames[K_COUNT] = {
+    "bgr2gray_k", "resize_k", "fast_nms_k", "select_k", "describe_k", "hamming_knn2_partial", "knn2_finalize",
+    "fmat_prepare_k", "fmat_solve_k", "fmat_score_k", "fmat_finalize_k", "ransac_select_k",
+    "pnp_prepare_k", "pnp_solve_k", "pnp_score_k", "pnp_finalize_k", "triangulate_k",
+    "ba_points_k", "ba_poses_k", "ba_final_k" };
+
+int prof_begin(mslam_ctx* ctx, int kid)
+{
+    Prof& p = ctx->prof;
+    if (!p.on || p.used >= p.kid.size()) return -1;
+    const int i = (int)p.used++;
+    p.kid[i] = kid;
+    (void)hipEventRecord(p.ev[2 * i], ctx->stream);
+    return i;
+}
+
+void prof_end(mslam_ctx* ctx, int pair)
+{
+    if (pair >= 0) (void)hipEventRecord(ctx->prof.ev[2 * pair + 1], ctx->stream);
+}
+
 extern "C" {
 
 int mslam_abi_version(void) { return MSLAM_ABI_VERSION; }
@@ -48,6 +69,7 @@ void mslam_destroy(mslam_ctx* ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     orb_plan_destroy(ctx);
+    for (hipEvent_t e : ctx->prof.ev) (void)hipEventDestroy(e);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->stage) (void)hipFree(ctx->stage);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -127,6 +149,43 @@ int mslam_event_elapsed_ms(mslam_ctx* ctx, void* a, void* b, float* ms)
     if (!ctx || !a || !b || !ms) return MSLAM_ERR_INVALID;
     HIP_TRY(ctx, hipEventSynchronize((hipEvent_t)b));
     HIP_TRY(ctx, hipEventElapsedTime(ms, (hipEvent_t)a, (hipEvent_t)b));
+    return MSLAM_OK;
+}
+
+// ---- per-kernel timing with HIP events on the context's stream
+int mslam_profile_enable(mslam_ctx* ctx, int max_launches)
+{
+    if (!ctx || max_launches < 0) return MSLAM_ERR_INVALID;
+    MSLAM_TRY(ctx_set_device(ctx));
+    Prof& p = ctx->prof;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    while (p.ev.size() < 2 * (size_t)max_launches) {
+        hipEvent_t e;
+        HIP_TRY(ctx, hipEventCreate(&e));
+        p.ev.push_back(e);
+    }
+    p.kid.assign(p.ev.size() / 2, -1);
+    p.used = 0;
+    p.on = max_launches > 0;
+    return MSLAM_OK;
+}
+
+int mslam_profile_kernel_count(void) { return K_COUNT; }
+const char* mslam_profile_kernel_name(int kid) { return (kid >= 0 && kid < K_COUNT) ? kKernelNames[kid] : ""; }
+
+// total milliseconds and launch count per kernel id since the last enable (syncs the stream)
+int mslam_profile_read(mslam_ctx* ctx, double* total_ms /*K_COUNT*/, int32_t* launches /*K_COUNT*/)
+{
+    if (!ctx || !total_ms || !launches) return MSLAM_ERR_INVALID;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (int k = 0; k < K_COUNT; k++) { total_ms[k] = 0.0; launches[k] = 0; }
+    Prof& p = ctx->prof;
+    for (size_t i = 0; i < p.used; i++) {
+        float ms = 0.f;
+        HIP_TRY(ctx, hipEventElapsedTime(&ms, p.ev[2 * i], p.ev[2 * i + 1]));
+        total_ms[p.kid[i]] += ms;
+        launches[p.kid[i]]++;
+    }
     return MSLAM_OK;
 }
 

@@ -154,8 +154,8 @@ int mslam_match_knn2_batch_dev(mslam_ctx* ctx, const uint8_t* q, const int32_t* 
     MSLAM_TRY(ctx_scratch(ctx, sizeof(uint2) * (size_t)B * nchunks * cap, &scr));
     uint2* part = (uint2*)scr;
     dim3 grid((cap + MATCH_THREADS * QPL - 1) / (MATCH_THREADS * QPL), nchunks, B);
-    hipLaunchKernelGGL(hamming_knn2_partial, grid, dim3(MATCH_THREADS), 0, ctx->stream, q, nq, t, nt, cap, nchunks, part);
-    hipLaunchKernelGGL(knn2_finalize, dim3(B), dim3(256), 0, ctx->stream, part, nq, nt, cap, nchunks, idx, dist,
+    LAUNCH(ctx, K_MATCH_PARTIAL, hamming_knn2_partial, grid, dim3(MATCH_THREADS), 0, q, nq, t, nt, cap, nchunks, part);
+    LAUNCH(ctx, K_MATCH_FINALIZE, knn2_finalize, dim3(B), dim3(256), 0, part, nq, nt, cap, nchunks, idx, dist,
                        ratio, m_query, m_train, m_dist, ratio > 0.f ? m_count : (int32_t*)nullptr);
     HIP_TRY(ctx, hipGetLastError());
     return MSLAM_OK;

@@ -734,7 +734,7 @@ int mslam_orb_extract_batch_dev(mslam_ctx* ctx, const uint8_t* imgs, int B, int 
         od.lv[0].frame_stride = frame_stride;
     } else {
         od.lv[0].img = pl->level0; od.lv[0].pitch = pl->level0_pitch; od.lv[0].frame_stride = pl->level0_fstride;
-        hipLaunchKernelGGL(bgr2gray_k, dim3((w + 255) / 256, h, B), dim3(256), 0, st, imgs, w, h, stride,
+        LAUNCH(ctx, K_GRAY, bgr2gray_k, dim3((w + 255) / 256, h, B), dim3(256), 0, imgs, w, h, stride,
                            (long long)frame_stride, channels, od.lv[0].img, od.lv[0].pitch, od.lv[0].frame_stride);
     }
     pl->last_l0 = od.lv[0].img; pl->last_l0_pitch = od.lv[0].pitch;
@@ -742,15 +742,15 @@ int mslam_orb_extract_batch_dev(mslam_ctx* ctx, const uint8_t* imgs, int B, int 
     for (int l = 1; l < od.L; l++) {
         const LevelDesc& s = od.lv[l - 1];
         const LevelDesc& d = od.lv[l];
-        hipLaunchKernelGGL(resize_k, dim3((d.w + 1023) / 1024, d.h, B), dim3(256), 0, st, s.img, s.pitch, s.frame_stride,
+        LAUNCH(ctx, K_RESIZE, resize_k, dim3((d.w + 1023) / 1024, d.h, B), dim3(256), 0, s.img, s.pitch, s.frame_stride,
                            d.img, d.w, d.h, d.pitch, d.frame_stride, d.xtab, d.ytab);
     }
     if (od.tiles_per_frame > 0)
-        hipLaunchKernelGGL(fast_nms_k, dim3(od.tiles_per_frame * B), dim3(FAST_THREADS), 0, st, od);
-    hipLaunchKernelGGL(select_k, dim3(od.L, B), dim3(SEL_THREADS), sizeof(uint2) * (size_t)od.max_kpts, st, od);
+        LAUNCH(ctx, K_FAST_NMS, fast_nms_k, dim3(od.tiles_per_frame * B), dim3(FAST_THREADS), 0, od);
+    LAUNCH(ctx, K_SELECT, select_k, dim3(od.L, B), dim3(SEL_THREADS), sizeof(uint2) * (size_t)od.max_kpts, od);
     DescArgs da{ kps, desc, n_out, status_dev, cap };
     const int max_total = cap < od.max_kpts * od.L ? cap : od.max_kpts * od.L;
-    hipLaunchKernelGGL(describe_k, dim3((max_total + DESC_WAVES - 1) / DESC_WAVES + 1, B), dim3(64 * DESC_WAVES), 0, st, od, da);
+    LAUNCH(ctx, K_DESCRIBE, describe_k, dim3((max_total + DESC_WAVES - 1) / DESC_WAVES + 1, B), dim3(64 * DESC_WAVES), 0, od, da);
     HIP_TRY(ctx, hipGetLastError());
     return MSLAM_OK;
 }

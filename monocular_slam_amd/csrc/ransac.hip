@@ -1169,11 +1169,11 @@ int mslam_fmat_ransac8_batch_dev(mslam_ctx* ctx, const double* x1, const double*
     a.counts = inlier_counts ? inlier_counts : (int32_t*)(base + o_cnt);
     a.best = best_h; a.F = F; a.status = status; a.n_inliers = n_inliers;
     hipStream_t st = ctx->stream;
-    hipLaunchKernelGGL(fmat_prepare_k, dim3(B), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(fmat_solve_k, dim3((H + 63) / 64, B), dim3(64), 0, st, a);
-    hipLaunchKernelGGL(fmat_score_k, dim3((H + HT - 1) / HT, B), dim3(SCORE_THREADS), 0, st, a);
-    hipLaunchKernelGGL(ransac_select_k, dim3(B), dim3(64), 0, st, a.counts, M, H, 8, prm->confidence, best_h, (int32_t*)nullptr);
-    hipLaunchKernelGGL(fmat_finalize_k, dim3(B), dim3(256), 0, st, a);
+    LAUNCH(ctx, K_FMAT_PREPARE, fmat_prepare_k, dim3(B), dim3(256), 0, a);
+    LAUNCH(ctx, K_FMAT_SOLVE, fmat_solve_k, dim3((H + 63) / 64, B), dim3(64), 0, a);
+    LAUNCH(ctx, K_FMAT_SCORE, fmat_score_k, dim3((H + HT - 1) / HT, B), dim3(SCORE_THREADS), 0, a);
+    LAUNCH(ctx, K_RANSAC_SELECT, ransac_select_k, dim3(B), dim3(64), 0, a.counts, M, H, 8, prm->confidence, best_h, (int32_t*)nullptr);
+    LAUNCH(ctx, K_FMAT_FINALIZE, fmat_finalize_k, dim3(B), dim3(256), 0, a);
     HIP_TRY(ctx, hipGetLastError());
     return MSLAM_OK;
 }
@@ -1241,11 +1241,11 @@ int mslam_pnp_ransac_batch_dev(mslam_ctx* ctx, const double* X, const double* x,
     a.best = best_h; a.best_cnt = (int32_t*)(base + o_bc);
     a.Rt = Rt; a.rvec = rvec; a.tvec = tvec; a.inliers = inliers; a.n_inliers = n_inliers; a.status = nullptr;
     hipStream_t st = ctx->stream;
-    hipLaunchKernelGGL(pnp_prepare_k, dim3((capP + 255) / 256, B), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(pnp_solve_k, dim3((H + 63) / 64, B), dim3(64), 0, st, a);
-    hipLaunchKernelGGL(pnp_score_k, dim3((H + HT - 1) / HT, B), dim3(SCORE_THREADS), 0, st, a);
-    hipLaunchKernelGGL(ransac_select_k, dim3(B), dim3(64), 0, st, a.counts, P, H, 4, prm->confidence, best_h, a.best_cnt);
-    hipLaunchKernelGGL(pnp_finalize_k, dim3(B), dim3(256), 0, st, a);
+    LAUNCH(ctx, K_PNP_PREPARE, pnp_prepare_k, dim3((capP + 255) / 256, B), dim3(256), 0, a);
+    LAUNCH(ctx, K_PNP_SOLVE, pnp_solve_k, dim3((H + 63) / 64, B), dim3(64), 0, a);
+    LAUNCH(ctx, K_PNP_SCORE, pnp_score_k, dim3((H + HT - 1) / HT, B), dim3(SCORE_THREADS), 0, a);
+    LAUNCH(ctx, K_RANSAC_SELECT, ransac_select_k, dim3(B), dim3(64), 0, a.counts, P, H, 4, prm->confidence, best_h, a.best_cnt);
+    LAUNCH(ctx, K_PNP_FINALIZE, pnp_finalize_k, dim3(B), dim3(256), 0, a);
     HIP_TRY(ctx, hipGetLastError());
     return MSLAM_OK;
 }
@@ -1325,7 +1325,7 @@ int mslam_triangulate(mslam_ctx* ctx, const double* x1, const double* x2, int n,
     HIP_TRY(ctx, hipMemcpyAsync(base + o_x1, x1, sizeof(double) * 2 * n, hipMemcpyHostToDevice, st));
     HIP_TRY(ctx, hipMemcpyAsync(base + o_x2, x2, sizeof(double) * 2 * n, hipMemcpyHostToDevice, st));
     HIP_TRY(ctx, hipMemsetAsync(base + o_n, 0, 16, st));
-    hipLaunchKernelGGL(triangulate_k, dim3((n + 63) / 64), dim3(64), 0, st, a);
+    LAUNCH(ctx, K_TRIANGULATE, triangulate_k, dim3((n + 63) / 64), dim3(64), 0, a);
     HIP_TRY(ctx, hipGetLastError());
     int32_t hn = 0;
     HIP_TRY(ctx, hipMemcpyAsync(X, base + o_X, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, st));
