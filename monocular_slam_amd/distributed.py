@@ -1,0 +1,59 @@
+"""Multi-GPU host logic: one process per GPU, torch.distributed (backend "nccl" = RCCL on ROCm; "gloo" in
+the CPU tests).
+
+The hot path shards by independent streams -- rank r owns streams r*B .. r*B+B-1 and nothing is exchanged
+(weak scaling).  The only collective is for the optional sharding of ONE RANSAC problem's hypotheses over
+ranks: each rank scores a contiguous slice of the sample table, the int32 inlier
+counts are all-gathered, and every rank computes the same global winner (max count, lowest global index).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def shard_range(n: int, rank: int, world: int) -> tuple[int, int]:
+    """Contiguous, balanced slice [lo, hi) of n items for `rank` (the first n % world ranks get one more)."""
+    base, rem = divmod(n, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def stream_ids(streams_per_rank: int, rank: int) -> range:
+    return range(rank * streams_per_rank, (rank + 1) * streams_per_rank)
+
+
+def allgather_counts(local_counts: np.ndarray, total: int, dist=None, device=None) -> np.ndarray:
+    """All-gather ragged int32 slices (shard_range order) into the full per-hypothesis count vector."""
+    local_counts = np.ascontiguousarray(local_counts, np.int32)
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        assert local_counts.shape[0] == total
+        return local_counts
+    import torch
+    world, rank = dist.get_world_size(), dist.get_rank()
+    width = -(-total // world)  # pad every slice to the same length: one fixed-size collective
+    buf = torch.full((width,), -1, dtype=torch.int32, device=device)
+    buf[: local_counts.shape[0]] = torch.from_numpy(local_counts).to(buf.device)
+    out = torch.empty((world, width), dtype=torch.int32, device=device)
+    dist.all_gather_into_tensor(out, buf) if hasattr(dist, "all_gather_into_tensor") and buf.is_cuda else \
+        dist.all_gather(list(out.unbind(0)), buf)
+    out = out.cpu().numpy()
+    parts = []
+    for r in range(world):
+        lo, hi = shard_range(total, r, world)
+        parts.append(out[r, : hi - lo])
+    return np.concatenate(parts)
+
+
+def global_winner(counts: np.ndarray) -> tuple[int, int]:
+    """max count, lowest index on ties (same rule as mslam_argmax_counts / ransac_select_k without confidence)."""
+    best = int(np.argmax(counts))  # numpy returns the first maximum
+    return best, int(counts[best])
+
+
+def max_over_ranks(value: float, dist=None, device=None) -> float:
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return value
+    import torch
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
