@@ -206,3 +206,49 @@ def ba_problem(n_poses: int, n_points: int, seed: int, K: np.ndarray = K_MINITAU
                 edge_pose=np.array(e_pose, dtype=np.int32), edge_point=np.array(e_point, dtype=np.int32),
                 obs=np.ascontiguousarray(np.array(obs)), info=np.array(info), intr=np.ascontiguousarray(intr),
                 huber_delta=float(np.float32(np.sqrt(5.99))))
+
+
+def smooth_depth(w: int, h: int, base: float = 6.0) -> np.ndarray:
+    """A smooth, clearly non-planar depth field for frame A (metres along the optical axis)."""
+    v, u = np.mgrid[0:h, 0:w].astype(np.float64)
+    return base + 2.2 * np.sin(u / (0.11 * w)) * np.cos(v / (0.13 * h)) + 2.0 * (u / w) - 1.5 * (v / h)
+
+
+def render_view(img_a: np.ndarray, depth_a: np.ndarray, K: np.ndarray, R: np.ndarray, t: np.ndarray, iters: int = 10) -> np.ndarray:
+    """Frame B of the rigid scene (texture img_a at depth depth_a in camera A) seen from pose (R, t): x_B = R x_A + t.
+
+    Backward warping: for every pixel of B the source pixel in A is found by fixed-point iteration on the forward
+    projection (small motion), then sampled bilinearly."""
+    h, w = img_a.shape
+    fx, fy, cx, cy = K[0, 0], K[1, 1], K[0, 2], K[1, 2]
+    vb, ub = np.mgrid[0:h, 0:w].astype(np.float64)
+    ua, va = ub.copy(), vb.copy()
+
+    def bil(a, u, v):
+        u = np.clip(u, 0, w - 1.001); v = np.clip(v, 0, h - 1.001)
+        u0 = np.floor(u).astype(int); v0 = np.floor(v).astype(int)
+        fu, fv = u - u0, v - v0
+        return (a[v0, u0] * (1 - fu) * (1 - fv) + a[v0, u0 + 1] * fu * (1 - fv) + a[v0 + 1, u0] * (1 - fu) * fv + a[v0 + 1, u0 + 1] * fu * fv)
+
+    for _ in range(iters):
+        z = bil(depth_a, ua, va)
+        xa = np.stack([(ua - cx) / fx * z, (va - cy) / fy * z, z], axis=-1)
+        xb = xa @ R.T + t
+        pu = fx * xb[..., 0] / xb[..., 2] + cx
+        pv = fy * xb[..., 1] / xb[..., 2] + cy
+        ua -= (pu - ub); va -= (pv - vb)
+    out = bil(img_a.astype(np.float64), ua, va)
+    return np.clip(np.rint(out), 0, 255).astype(np.uint8)
+
+
+def rigid_sequence(w: int, h: int, seed: int, n_frames: int = 3, K: np.ndarray = K_TUM1):
+    """C0: frame 0 = textured frame; frames 1.. = the same scene from small known motions. Returns frames, poses (R, t)."""
+    a = textured_frame(w, h, seed)
+    depth = smooth_depth(w, h)
+    frames, poses = [a], [(np.eye(3), np.zeros(3))]
+    for i in range(1, n_frames):
+        R = rodrigues(np.array([0.012 * i, 0.03 * i, -0.02 * i]))
+        t = np.array([0.22 * i, -0.10 * i, 0.16 * i])
+        frames.append(render_view(a, depth, K, R, t))
+        poses.append((R, t))
+    return np.stack(frames), poses, depth

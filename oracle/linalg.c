@@ -101,7 +101,9 @@ void orc_svd3(const double A[9], double U[9], double s[3], double Vt[9])
     double smax = s[0] > 0 ? s[0] : 1.0;
     int have[3] = { 0, 0, 0 };
     for (int c = 0; c < 3; c++) {
-        if (s[c] > 1e-12 * smax) {
+        /* eigenvalues of A^T A carry an absolute error of about eps*|A|^2, so singular values below
+         * sqrt(eps)*smax are noise: treat them as zero and complete U by orthogonality */
+        if (s[c] > 1e-6 * smax) {
             for (int r = 0; r < 3; r++)
                 u[c][r] = (A[r * 3 + 0] * vcol[c][0] + A[r * 3 + 1] * vcol[c][1] + A[r * 3 + 2] * vcol[c][2]) / s[c];
             have[c] = 1;
