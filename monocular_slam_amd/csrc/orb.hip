@@ -55,7 +55,7 @@ struct LevelDesc {
     int tiles_x, tiles_y, tile_base;   // tile_base: first tile index of this level in the all-level grid
     int cand_cap; uint32_t* cand; uint32_t* candA; float* respA;
     int nfeat; float sf, inv_sf;
-    int4* xtab; int4* ytab;            // resize tables for producing THIS level from l-1
+    int2* xtab; int4* ytab;            // resize tables for producing THIS level from l-1
 };
 
 struct OrbDev {
@@ -79,31 +79,76 @@ __global__ void bgr2gray_k(const uint8_t* __restrict__ src, int w, int h, int st
     dst[b * dfstride + (size_t)y * dpitch + x] = (uint8_t)v;
 }
 
-// 4 destination pixels per thread, packed 32-bit store
+// A workgroup produces a 256 x 8 destination tile: the source footprint (<= ~310 x 11 px at scale 1.2) is staged in
+// LDS with coalesced aligned dword loads (byte gathers from global memory are VMEM-issue bound: ~22 CU-cycles per
+// wave-instruction), then each lane computes 4 px x 2 rows from LDS bytes and writes packed 32-bit words.
+// Column table entry {sx0 | sx1 << 16, a0 | a1 << 16}; row table entry {sy0, sy1, b0, b1} (wave-uniform).
+constexpr int RS_TW = 256, RS_TH = 8, RS_LDS_DW = 4096;
 __global__ __launch_bounds__(256)
 void resize_k(const uint8_t* __restrict__ src, int spitch, long long sfstride,
               uint8_t* __restrict__ dst, int dw, int dh, int dpitch, long long dfstride,
-              const int4* __restrict__ xtab, const int4* __restrict__ ytab)
+              const int2* __restrict__ xtab, const int4* __restrict__ ytab)
 {
-    const int x4 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
-    const int y = blockIdx.y, b = blockIdx.z;
-    if (x4 >= dw) return;
-    const int4 yt = ytab[y]; // {sy0, sy1, b0, b1}
-    const uint8_t* r0 = src + b * sfstride + (size_t)yt.x * spitch;
-    const uint8_t* r1 = src + b * sfstride + (size_t)yt.y * spitch;
-    uint32_t out = 0;
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        int x = x4 + i;
-        if (x < dw) {
-            const int4 xt = xtab[x]; // {sx0, sx1, a0, a1}
-            int S0 = r0[xt.x] * xt.z + r0[xt.y] * xt.w;
-            int S1 = r1[xt.x] * xt.z + r1[xt.y] * xt.w;
-            int v = (((yt.z * (S0 >> 4)) >> 16) + ((yt.w * (S1 >> 4)) >> 16) + 2) >> 2;
-            out |= (uint32_t)(v & 255) << (8 * i);
+    __shared__ uint32_t s_src[RS_LDS_DW];
+    const int tid = threadIdx.x, b = blockIdx.z;
+    const int x0 = blockIdx.x * RS_TW, y0 = blockIdx.y * RS_TH;
+    const int xl = min(x0 + RS_TW, dw) - 1, yl = min(y0 + RS_TH, dh) - 1;
+    // source footprint of the tile (tables are monotone)
+    const int sx_lo = xtab[x0].x & 0xFFFF, sx_hi = (int)((unsigned)xtab[xl].x >> 16);
+    const int sy_lo = ytab[y0].x, sy_hi = ytab[yl].y;
+    const int sxa = sx_lo & ~3;
+    const int ndw = ((sx_hi - sxa) >> 2) + 1, nrows = sy_hi - sy_lo + 1;
+    const bool use_lds = ndw * nrows <= RS_LDS_DW; // always true for pyramid scales <= ~3
+    const uint8_t* sb = src + b * sfstride;
+    if (use_lds) {
+        const int max_dw = spitch / 4 - 1;
+        for (int i = tid; i < ndw * nrows; i += 256) {
+            const int r = i / ndw, c = i - r * ndw;
+            s_src[i] = reinterpret_cast<const uint32_t*>(sb + (size_t)(sy_lo + r) * spitch)[min(sxa / 4 + c, max_dw)];
         }
     }
-    *reinterpret_cast<uint32_t*>(dst + b * dfstride + (size_t)y * dpitch + x4) = out;
+    __syncthreads();
+    const int tx = tid & 63, ty = tid >> 6;
+    const int x4 = x0 + tx * 4;
+    if (x4 >= dw) return;
+    int sx0[4], sx1[4], a0[4], a1[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int2 t = xtab[min(x4 + i, dw - 1)];
+        sx0[i] = t.x & 0xFFFF; sx1[i] = (int)((unsigned)t.x >> 16); a0[i] = t.y & 0xFFFF; a1[i] = (int)((unsigned)t.y >> 16);
+    }
+    uint8_t* db = dst + b * dfstride;
+    const uint8_t* lds = reinterpret_cast<const uint8_t*>(s_src);
+    const int lpitch = ndw * 4;
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        const int y = y0 + ty * 2 + r;
+        if (y >= dh) break;
+        const int4 yt = ytab[y]; // {sy0, sy1, b0, b1}
+        uint32_t out = 0;
+        if (use_lds) {
+            const uint8_t* r0 = lds + (yt.x - sy_lo) * lpitch - sxa;
+            const uint8_t* r1 = lds + (yt.y - sy_lo) * lpitch - sxa;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int S0 = r0[sx0[i]] * a0[i] + r0[sx1[i]] * a1[i];
+                const int S1 = r1[sx0[i]] * a0[i] + r1[sx1[i]] * a1[i];
+                const int v = (((yt.z * (S0 >> 4)) >> 16) + ((yt.w * (S1 >> 4)) >> 16) + 2) >> 2;
+                out |= (uint32_t)(v & 255) << (8 * i);
+            }
+        } else {
+            const uint8_t* r0 = sb + (size_t)yt.x * spitch;
+            const uint8_t* r1 = sb + (size_t)yt.y * spitch;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int S0 = r0[sx0[i]] * a0[i] + r0[sx1[i]] * a1[i];
+                const int S1 = r1[sx0[i]] * a0[i] + r1[sx1[i]] * a1[i];
+                const int v = (((yt.z * (S0 >> 4)) >> 16) + ((yt.w * (S1 >> 4)) >> 16) + 2) >> 2;
+                out |= (uint32_t)(v & 255) << (8 * i);
+            }
+        }
+        *reinterpret_cast<uint32_t*>(db + (size_t)y * dpitch + x4) = out;
+    }
 }
 
 // ---------------------------------------------------------------- K2: FAST-9/16 + NMS
@@ -643,7 +688,7 @@ static int orb_plan_get(mslam_ctx* ctx, int w, int h, int B, int channels, const
         off_cand[l] = reserve(sizeof(uint32_t) * (size_t)lv.cand_cap * B);
         off_candA[l] = reserve(sizeof(uint32_t) * (size_t)lv.cand_cap * B);
         off_resp[l] = reserve(sizeof(float) * (size_t)lv.cand_cap * B);
-        off_xt[l] = reserve(sizeof(int4) * (size_t)lv.w);
+        off_xt[l] = reserve(sizeof(int2) * (size_t)lv.w);
         off_yt[l] = reserve(sizeof(int4) * (size_t)lv.h);
     }
     od.tiles_per_frame = tile_base;
@@ -667,24 +712,25 @@ static int orb_plan_get(mslam_ctx* ctx, int w, int h, int B, int channels, const
         lv.cand = (uint32_t*)(base + off_cand[l]);
         lv.candA = (uint32_t*)(base + off_candA[l]);
         lv.respA = (float*)(base + off_resp[l]);
-        lv.xtab = (int4*)(base + off_xt[l]);
+        lv.xtab = (int2*)(base + off_xt[l]);
         lv.ytab = (int4*)(base + off_yt[l]);
         if (l == 0) continue;
         // resize(INTER_LINEAR) coefficient tables for level l-1 -> l (OpenCV 2.4.13 imgwarp.cpp)
         const int sw = od.lv[l - 1].w, sh = od.lv[l - 1].h, dw = lv.w, dh = lv.h;
         const double inv_scale_x = (double)dw / sw, inv_scale_y = (double)dh / sh;
         const double scale_x = 1. / inv_scale_x, scale_y = 1. / inv_scale_y;
-        tab.assign((size_t)dw, make_int4(0, 0, 0, 0));
+        std::vector<int2> xt((size_t)dw);
         for (int dx = 0; dx < dw; dx++) {
             float fx = (float)((dx + 0.5) * scale_x - 0.5);
             int sx = cv_floor_host(fx);
             fx -= sx;
             if (sx < 0) { fx = 0; sx = 0; }
             if (sx >= sw - 1) { fx = 0; sx = sw - 1; }
-            tab[dx] = make_int4(sx, sx + 1 < sw ? sx + 1 : sx, sat_short_host(cv_round_host((1.f - fx) * 2048)),
-                                sat_short_host(cv_round_host(fx * 2048)));
+            const int sx1 = sx + 1 < sw ? sx + 1 : sx;
+            const int a0 = sat_short_host(cv_round_host((1.f - fx) * 2048)), a1 = sat_short_host(cv_round_host(fx * 2048));
+            xt[(size_t)dx] = make_int2(sx | (sx1 << 16), (a0 & 0xFFFF) | (a1 << 16)); // 0 <= a0, a1 <= 2048
         }
-        HIP_TRY(ctx, hipMemcpy(lv.xtab, tab.data(), sizeof(int4) * (size_t)dw, hipMemcpyHostToDevice));
+        HIP_TRY(ctx, hipMemcpy(lv.xtab, xt.data(), sizeof(int2) * (size_t)dw, hipMemcpyHostToDevice));
         tab.assign((size_t)dh, make_int4(0, 0, 0, 0));
         for (int dy = 0; dy < dh; dy++) {
             float fy = (float)((dy + 0.5) * scale_y - 0.5);
@@ -742,7 +788,7 @@ int mslam_orb_extract_batch_dev(mslam_ctx* ctx, const uint8_t* imgs, int B, int 
     for (int l = 1; l < od.L; l++) {
         const LevelDesc& s = od.lv[l - 1];
         const LevelDesc& d = od.lv[l];
-        LAUNCH(ctx, K_RESIZE, resize_k, dim3((d.w + 1023) / 1024, d.h, B), dim3(256), 0, s.img, s.pitch, s.frame_stride,
+        LAUNCH(ctx, K_RESIZE, resize_k, dim3((d.w + RS_TW - 1) / RS_TW, (d.h + RS_TH - 1) / RS_TH, B), dim3(256), 0, s.img, s.pitch, s.frame_stride,
                            d.img, d.w, d.h, d.pitch, d.frame_stride, d.xtab, d.ytab);
     }
     if (od.tiles_per_frame > 0)

@@ -439,21 +439,29 @@ void ransac_select_k(const int32_t* __restrict__ counts, const int32_t* __restri
     if (lane == 0) { best_out[b] = best; if (best_cnt_out) best_cnt_out[b] = maxgood; }
 }
 
-// block-wide sum of NV doubles per thread, fixed tree order (deterministic)
-template <int NV>
-__device__ void block_reduce(double (&v)[NV], double* s_red /*[NV][256]*/, int tid)
+// block-wide (NT threads) sum of NV doubles per thread in a fixed order (deterministic, no atomics): values are
+// parked in LDS (s_red: NV * NT doubles), value q is summed by wave q % NW (each lane adds NT/64 entries, then a
+// butterfly over the wave).  Two barriers per reduction.
+template <int NV, int NT>
+__device__ void block_reduce(double (&v)[NV], double* s_red, int tid)
 {
+    constexpr int NW = NT / 64;
 #pragma unroll
-    for (int k = 0; k < NV; k++) s_red[k * 256 + tid] = v[k];
+    for (int k = 0; k < NV; k++) s_red[k * NT + tid] = v[k];
     __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if (tid < o)
+    const int wave = tid >> 6, lane = tid & 63;
+    for (int q = wave; q < NV; q += NW) {
+        const double* r = s_red + q * NT;
+        double t = r[lane];
 #pragma unroll
-            for (int k = 0; k < NV; k++) s_red[k * 256 + tid] += s_red[k * 256 + tid + o];
-        __syncthreads();
+        for (int w = 1; w < NW; w++) t += r[lane + 64 * w];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
+        if (lane == 0) s_red[q * NT] = t; // row q is only touched by this wave
     }
+    __syncthreads();
 #pragma unroll
-    for (int k = 0; k < NV; k++) v[k] = s_red[k * 256];
+    for (int k = 0; k < NV; k++) v[k] = s_red[k * NT];
     __syncthreads();
 }
 
@@ -505,7 +513,7 @@ void fmat_finalize_k(FmatArgs a)
         double acc[4] = { 0, 0, 0, 0 };
         for (int i = tid; i < M; i += 256)
             if (status[i]) { acc[0] += x1[2 * i]; acc[1] += x1[2 * i + 1]; acc[2] += x2[2 * i]; acc[3] += x2[2 * i + 1]; }
-        block_reduce<4>(acc, s_red, tid);
+        block_reduce<4, 256>(acc, s_red, tid);
         const double t = 1. / n;
         c0x = acc[0] * t; c0y = acc[1] * t; c1x = acc[2] * t; c1y = acc[3] * t;
         double sc[2] = { 0, 0 };
@@ -516,7 +524,7 @@ void fmat_finalize_k(FmatArgs a)
                 dx = x2[2 * i] - c1x; dy = x2[2 * i + 1] - c1y;
                 sc[1] += sqrt(dx * dx + dy * dy);
             }
-        block_reduce<2>(sc, s_red, tid);
+        block_reduce<2, 256>(sc, s_red, tid);
         s0 = sc[0] * t; s1 = sc[1] * t;
         if (s0 < (double)FLT_EPSILON || s1 < (double)FLT_EPSILON) { if (tid < 9) Fout[tid] = 0.0; return; }
         s0 = sqrt(2.) / s0; s1 = sqrt(2.) / s1;
@@ -544,7 +552,7 @@ void fmat_finalize_k(FmatArgs a)
 #pragma unroll
             for (int k = 0; k < 9; k++) acc[k] += rr * r[k];
         }
-        block_reduce<9>(acc, s_red, tid);
+        block_reduce<9, 256>(acc, s_red, tid);
         if (tid == 0)
             for (int k = 0; k < 9; k++) s_A[r0 * 9 + k] = acc[k];
         __syncthreads();
@@ -871,61 +879,77 @@ void pnp_solve_k(PnpArgs a)
     for (int e = 0; e < 12; e++) mo[e] = bestRt[e]; // all zero = no hypothesis
 }
 
+// Scoring: a workgroup owns PNP_HPB hypotheses (poses staged in LDS) and its lanes keep PNP_PT points each in
+// registers (256 x 8 = 2048 points per pass), so a point is loaded once per workgroup and every hypothesis is
+// evaluated against PNP_PT independent projections per lane (ILP hides the f64 divide latency).  Votes are
+// __ballot + popcount per point slot, summed per hypothesis in LDS.
+constexpr int PNP_HPB = 32;
+constexpr int PNP_PT = 8;
+
 template <bool HAS_DIST>
-__device__ __forceinline__ void pnp_score_body(const PnpArgs& a, int b, int h0, int tid, int lane, double (*s_Rt)[12], int* s_cnt)
+__device__ __forceinline__ void pnp_score_body(const PnpArgs& a, int b, int h0, int nh, int tid, int lane, const double (*s_Rt)[12],
+                                               const int* s_valid, int* s_cnt)
 {
     const int P = a.P[b];
     const double* K = a.K + b * 9;
     const double* k = a.dist + b * 8;
     const double fx = K[0], fy = K[4], cx = K[2], cy = K[5];
-    int cnt[HT];
-#pragma unroll
-    for (int q = 0; q < HT; q++) cnt[q] = 0;
     const double* Xw = a.X + (size_t)b * a.capP * 3;
     const double* x = a.x + (size_t)b * a.capP * 2;
-    for (int i0 = 0; i0 < P; i0 += SCORE_THREADS) {
-        const int i = i0 + tid;
-        const bool live = i < P;
-        const int ic = live ? i : 0;
-        const double X = Xw[3 * ic], Y = Xw[3 * ic + 1], Z = Xw[3 * ic + 2];
-        const double ox = x[2 * ic], oy = x[2 * ic + 1];
+    for (int c0 = 0; c0 < P; c0 += SCORE_THREADS * PNP_PT) {
+        double X[PNP_PT], Y[PNP_PT], Z[PNP_PT], ox[PNP_PT], oy[PNP_PT];
+        bool live[PNP_PT];
 #pragma unroll
-        for (int q = 0; q < HT; q++) {
-            double u, v;
-            project_pt(s_Rt[q], fx, fy, cx, cy, k, HAS_DIST, X, Y, Z, u, v);
-            const double dx = ox - u, dy = oy - v;
-            // sqrt(d2) < thr  <=>  d2 < thr2cut  (thr2cut = smallest double whose sqrt is >= thr)
-            const bool in = live && (dx * dx + dy * dy < a.thr2cut);
-            cnt[q] += __popcll(__ballot(in));
+        for (int j = 0; j < PNP_PT; j++) {
+            const int i = c0 + j * SCORE_THREADS + tid;
+            live[j] = i < P;
+            const int ic = live[j] ? i : 0;
+            X[j] = Xw[3 * ic]; Y[j] = Xw[3 * ic + 1]; Z[j] = Xw[3 * ic + 2];
+            ox[j] = x[2 * ic]; oy[j] = x[2 * ic + 1];
+        }
+        for (int q = 0; q < nh; q++) {
+            if (!s_valid[q]) continue; // wave-uniform
+            double Rt[12];
+#pragma unroll
+            for (int e = 0; e < 12; e++) Rt[e] = s_Rt[q][e];
+            int cnt = 0;
+#pragma unroll
+            for (int j = 0; j < PNP_PT; j++) {
+                double u, v;
+                project_pt(Rt, fx, fy, cx, cy, k, HAS_DIST, X[j], Y[j], Z[j], u, v);
+                const double dx = ox[j] - u, dy = oy[j] - v;
+                // sqrt(d2) < thr  <=>  d2 < thr2cut  (thr2cut = smallest double whose sqrt is >= thr)
+                const bool in = live[j] && (dx * dx + dy * dy < a.thr2cut);
+                cnt += __popcll(__ballot(in));
+            }
+            if (lane == 0) atomicAdd(&s_cnt[q], cnt);
         }
     }
-    if (lane == 0)
-#pragma unroll
-        for (int q = 0; q < HT; q++) atomicAdd(&s_cnt[q], cnt[q]);
 }
 
 __global__ __launch_bounds__(SCORE_THREADS)
 void pnp_score_k(PnpArgs a)
 {
-    const int b = blockIdx.y, h0 = blockIdx.x * HT, tid = threadIdx.x, lane = tid & 63;
-    __shared__ double s_Rt[HT][12];
-    __shared__ int s_cnt[HT];
-    __shared__ int s_valid[HT];
-    if (tid < HT * 12) {
-        int hh = tid / 12, e = tid % 12;
-        s_Rt[hh][e] = (h0 + hh < a.H) ? a.models[((size_t)b * a.H + h0 + hh) * 12 + e] : 0.0;
+    const int b = blockIdx.y, h0 = blockIdx.x * PNP_HPB, tid = threadIdx.x, lane = tid & 63;
+    const int nh = min(PNP_HPB, a.H - h0);
+    __shared__ double s_Rt[PNP_HPB][12];
+    __shared__ int s_cnt[PNP_HPB];
+    __shared__ int s_valid[PNP_HPB];
+    for (int i = tid; i < PNP_HPB * 12; i += SCORE_THREADS) {
+        const int hh = i / 12, e = i % 12;
+        s_Rt[hh][e] = (hh < nh) ? a.models[((size_t)b * a.H + h0 + hh) * 12 + e] : 0.0;
     }
-    if (tid < HT) s_cnt[tid] = 0;
+    if (tid < PNP_HPB) s_cnt[tid] = 0;
     __syncthreads();
-    if (tid < HT) { // a hypothesis without a pose is all zero (row 2 of a rotation cannot be zero)
+    if (tid < PNP_HPB) // a hypothesis without a pose is all zero (row 2 of a rotation cannot be zero)
         s_valid[tid] = !(s_Rt[tid][8] == 0.0 && s_Rt[tid][9] == 0.0 && s_Rt[tid][10] == 0.0);
-    }
+    __syncthreads();
     const double* k = a.dist + b * 8;
     const bool has_dist = (k[0] != 0.0) | (k[1] != 0.0) | (k[2] != 0.0) | (k[3] != 0.0) | (k[4] != 0.0) | (k[5] != 0.0) | (k[6] != 0.0) | (k[7] != 0.0);
-    if (has_dist) pnp_score_body<true>(a, b, h0, tid, lane, s_Rt, s_cnt);
-    else pnp_score_body<false>(a, b, h0, tid, lane, s_Rt, s_cnt);
+    if (has_dist) pnp_score_body<true>(a, b, h0, nh, tid, lane, s_Rt, s_valid, s_cnt);
+    else pnp_score_body<false>(a, b, h0, nh, tid, lane, s_Rt, s_valid, s_cnt);
     __syncthreads();
-    if (tid < HT && h0 + tid < a.H) a.counts[(size_t)b * a.H + h0 + tid] = s_valid[tid] ? s_cnt[tid] : 0;
+    if (tid < nh) a.counts[(size_t)b * a.H + h0 + tid] = s_valid[tid] ? s_cnt[tid] : 0;
 }
 
 __device__ void R_to_rodrigues(const double* R, double* r)
@@ -952,7 +976,8 @@ __device__ void R_to_rodrigues(const double* R, double* r)
     r[0] = rx * vth; r[1] = ry * vth; r[2] = rz * vth;
 }
 
-__global__ __launch_bounds__(256)
+constexpr int FIN_THREADS = 256;
+__global__ __launch_bounds__(FIN_THREADS)
 void pnp_finalize_k(PnpArgs a)
 {
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -961,18 +986,18 @@ void pnp_finalize_k(PnpArgs a)
     const int bc = a.best_cnt[b];
     uint8_t* mask = a.inliers + (size_t)b * a.capP;
     double* Rt_out = a.Rt + (size_t)b * 12;
-    __shared__ double s_red[27 * 256];
+    __shared__ double s_red[27 * FIN_THREADS];
     __shared__ double s_Rt[12];
-    __shared__ int s_n, s_fail;
+    __shared__ int s_n, s_fail, s_done;
     if (best < 0 || bc < a.min_inliers) {
-        for (int i = tid; i < P; i += 256) mask[i] = 0;
+        for (int i = tid; i < P; i += FIN_THREADS) mask[i] = 0;
         if (tid < 12) Rt_out[tid] = 0.0;
         if (tid < 3) { if (a.rvec) a.rvec[b * 3 + tid] = 0.0; if (a.tvec) a.tvec[b * 3 + tid] = 0.0; }
         if (tid == 0) { a.n_inliers[b] = 0; if (a.status) a.status[b] = MSLAM_ERR_DEGENERATE; }
         return;
     }
     if (tid < 12) s_Rt[tid] = a.models[((size_t)b * a.H + best) * 12 + tid];
-    if (tid == 0) { s_n = 0; s_fail = 0; }
+    if (tid == 0) { s_n = 0; s_fail = 0; s_done = 0; }
     __syncthreads();
     const double* K = a.K + b * 9;
     const double* k = a.dist + b * 8;
@@ -981,7 +1006,7 @@ void pnp_finalize_k(PnpArgs a)
     const double* Xw = a.X + (size_t)b * a.capP * 3;
     const double* x = a.x + (size_t)b * a.capP * 2;
     int my = 0;
-    for (int i = tid; i < P; i += 256) {
+    for (int i = tid; i < P; i += FIN_THREADS) {
         double u, v;
         project_pt(s_Rt, fx, fy, cx, cy, k, has_dist, Xw[3 * i], Xw[3 * i + 1], Xw[3 * i + 2], u, v);
         double dx = x[2 * i] - u, dy = x[2 * i + 1] - v;
@@ -997,7 +1022,7 @@ void pnp_finalize_k(PnpArgs a)
         double acc[27];
 #pragma unroll
         for (int q = 0; q < 27; q++) acc[q] = 0.0;
-        for (int i = tid; i < P; i += 256) {
+        for (int i = tid; i < P; i += FIN_THREADS) {
             if (!mask[i]) continue;
             const double Xi0 = Xw[3 * i], Xi1 = Xw[3 * i + 1], Xi2 = Xw[3 * i + 2];
             double px = s_Rt[0] * Xi0 + s_Rt[1] * Xi1 + s_Rt[2] * Xi2 + s_Rt[3];
@@ -1035,7 +1060,7 @@ void pnp_finalize_k(PnpArgs a)
 #pragma unroll
             for (int r = 0; r < 6; r++) acc[21 + r] += Ju[r] * ru + Jv[r] * rv;
         }
-        block_reduce<27>(acc, s_red, tid);
+        block_reduce<27, FIN_THREADS>(acc, s_red, tid);
         if (tid == 0) {
             double Hm[36], g[6], Lc[36], yv[6], d[6];
             int q = 0;
@@ -1067,10 +1092,12 @@ void pnp_finalize_k(PnpArgs a)
                     nRt[i * 4 + 3] += V[i * 3] * d[3] + V[i * 3 + 1] * d[4] + V[i * 3 + 2] * d[5];
                 }
                 for (int i = 0; i < 12; i++) s_Rt[i] = nRt[i];
+                // converged: the step is below double resolution of the pose
+                if (d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3] + d[4] * d[4] + d[5] * d[5] < 1e-20) s_done = 1;
             }
         }
         __syncthreads();
-        if (s_fail) break;
+        if (s_fail || s_done) break;
     }
     if (tid == 0) {
         for (int i = 0; i < 12; i++) Rt_out[i] = s_Rt[i];
@@ -1243,9 +1270,9 @@ int mslam_pnp_ransac_batch_dev(mslam_ctx* ctx, const double* X, const double* x,
     hipStream_t st = ctx->stream;
     LAUNCH(ctx, K_PNP_PREPARE, pnp_prepare_k, dim3((capP + 255) / 256, B), dim3(256), 0, a);
     LAUNCH(ctx, K_PNP_SOLVE, pnp_solve_k, dim3((H + 63) / 64, B), dim3(64), 0, a);
-    LAUNCH(ctx, K_PNP_SCORE, pnp_score_k, dim3((H + HT - 1) / HT, B), dim3(SCORE_THREADS), 0, a);
+    LAUNCH(ctx, K_PNP_SCORE, pnp_score_k, dim3((H + PNP_HPB - 1) / PNP_HPB, B), dim3(SCORE_THREADS), 0, a);
     LAUNCH(ctx, K_RANSAC_SELECT, ransac_select_k, dim3(B), dim3(64), 0, a.counts, P, H, 4, prm->confidence, best_h, a.best_cnt);
-    LAUNCH(ctx, K_PNP_FINALIZE, pnp_finalize_k, dim3(B), dim3(256), 0, a);
+    LAUNCH(ctx, K_PNP_FINALIZE, pnp_finalize_k, dim3(B), dim3(FIN_THREADS), 0, a);
     HIP_TRY(ctx, hipGetLastError());
     return MSLAM_OK;
 }

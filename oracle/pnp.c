@@ -397,6 +397,8 @@ int orc_pnp_refine(const double* X, const double* x, int P, const uint8_t* mask,
             nRt[i * 4 + 3] += V[i * 3] * d[3] + V[i * 3 + 1] * d[4] + V[i * 3 + 2] * d[5];
         }
         memcpy(Rt, nRt, sizeof(nRt));
+        /* converged: the step is below double resolution of the pose (quadratic convergence: usually 3-4 rounds) */
+        if (d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3] + d[4] * d[4] + d[5] * d[5] < 1e-20) break;
     }
     return 0;
 }
