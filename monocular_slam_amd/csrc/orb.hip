@@ -10,7 +10,7 @@
 //                                      gray frame when it is 1-channel and 4-byte aligned
 //   cand[l]    u32 [B][cap_l]         FAST corners after NMS: score<<24 | y<<12 | x
 //   candA[l]   u32 [B][cap_l]         survivors of retainBest(2n) + respA f32 (Harris)
-//   hist       u32 [B][L][256]        FAST score histogram,  cnt u32 [B][L]
+//   cnt        u32 [B][L]             candidate counts (the FAST score histogram is rebuilt in LDS by select_k)
 //   sel        u32x2 [B][L][max_kpts] final per-level keypoints (key, response), row-major
 //   cap_l = ceil(roi_w/2)*ceil(roi_h/2): NMS survivors are never 8-adjacent, so the
 //   candidate list cannot overflow.
@@ -31,6 +31,7 @@
 // with -ffp-contract=off); cvRound = round-half-even (__float2int_rn / rint).
 #include "common.h"
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 namespace {
@@ -43,10 +44,13 @@ __constant__ int c_umax[16] = { 15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 
 // 7x7 sigma=2 Gaussian, 8-bit fixed point (getGaussianKernel(7,2,CV_32F) * 256, cvRound)
 __constant__ int c_gk[7] = { 18, 34, 49, 55, 49, 34, 18 };
 
-constexpr int FT_W = 64, FT_H = 32;           // FAST output tile
-constexpr int FP_W = FT_W + 8, FP_H = FT_H + 8; // pixel tile (halo 4)
-constexpr int FP_PITCH = 80;                  // LDS row pitch in bytes (20 dwords)
-constexpr int FS_W = FT_W + 2, FS_H = FT_H + 2; // score tile (halo 1)
+// FAST tile geometry: the SCORE region (outputs + 1 px ring for NMS) is 128 x 32 so that a row of it is 32 groups of
+// 4 pixels = 32 LDS dwords; outputs are the inner 126 x 30.  The pixel tile (score region + 3 px ring) is staged so
+// that score column 0 sits on a dword boundary: LDS byte (c + 1) of a row holds tile column c.
+constexpr int FS_W = 128, FS_H = 32;              // score region
+constexpr int FT_W = FS_W - 2, FT_H = FS_H - 2;   // outputs per tile (126 x 30)
+constexpr int FP_H = FS_H + 6;                    // pixel tile rows (38)
+constexpr int FP_PITCH = 136;                     // LDS row pitch in bytes (34 dwords: 134 columns + 2 pad)
 constexpr int FAST_THREADS = 256;
 
 struct LevelDesc {
@@ -60,8 +64,7 @@ struct LevelDesc {
 
 struct OrbDev {
     LevelDesc lv[MSLAM_MAX_LEVELS];
-    int L, B, max_kpts, edge, fast_thr, score_type, tiles_per_frame;
-    uint32_t* hist;   // [B][L][256]
+    int L, B, max_kpts, edge, fast_thr, score_type, tiles_per_frame, ablate;
     uint32_t* cnt;    // [B][L] candidate counts
     uint2* sel;       // [B][L][max_kpts]
     int32_t* sel_cnt; // [B][L]
@@ -180,14 +183,16 @@ __device__ __forceinline__ int fast_exact_score(const int* d)
     return max(amax, -bmin) - 1;
 }
 
+__device__ __forceinline__ uint32_t byte_of(uint32_t w, int k) { return (w >> (8 * k)) & 255u; }
+
 __global__ __launch_bounds__(FAST_THREADS)
 void fast_nms_k(OrbDev od)
 {
     __shared__ uint32_t s_pix[FP_H * FP_PITCH / 4];
-    __shared__ uint8_t s_score[FS_H * FS_W + 4];
+    __shared__ uint8_t s_score[FS_H * FS_W];
     __shared__ uint16_t s_list[FS_H * FS_W];
-    __shared__ uint32_t s_emit[FT_W * FT_H / 4 + 64];
-    __shared__ int s_n1, s_n2, s_ne, s_base;
+    __shared__ uint32_t s_emit[(FT_W / 2) * (FT_H / 2) + 64];
+    __shared__ int s_n1, s_ne, s_base;
 
     // tile -> (frame, level, tx, ty): blocks of one frame are consecutive
     const int b = blockIdx.x / od.tiles_per_frame;
@@ -198,57 +203,85 @@ void fast_nms_k(OrbDev od)
     t -= lv.tile_base;
     const int tx = t % lv.tiles_x, ty = t / lv.tiles_x;
     const int ox = lv.roi_x0 + tx * FT_W, oy = lv.roi_y0 + ty * FT_H; // first output pixel
-    const int px0 = ox - 4, py0 = oy - 4;                             // pixel tile origin
     const uint8_t* img = lv.img + b * lv.frame_stride;
     const int tid = threadIdx.x;
 
-    if (tid == 0) { s_n1 = 0; s_n2 = 0; s_ne = 0; }
-    for (int i = tid; i < (FS_H * FS_W + 4) / 4; i += FAST_THREADS) reinterpret_cast<uint32_t*>(s_score)[i] = 0;
-    // stage the pixel tile with aligned dword loads; xo = misalignment of the tile origin
-    const int xa = px0 & ~3, xo = px0 & 3;
-    const int max_dw = lv.pitch / 4 - 1;
-    for (int i = tid; i < FP_H * (FP_PITCH / 4); i += FAST_THREADS) {
-        int r = i / (FP_PITCH / 4), c = i % (FP_PITCH / 4);
-        int gy = min(py0 + r, lv.h - 1);
-        int gdw = min(xa / 4 + c, max_dw);
-        s_pix[i] = reinterpret_cast<const uint32_t*>(img + (size_t)gy * lv.pitch)[gdw];
+    if (tid == 0) { s_n1 = 0; s_ne = 0; }
+    for (int i = tid; i < FS_H * FS_W / 4; i += FAST_THREADS) reinterpret_cast<uint32_t*>(s_score)[i] = 0;
+    // ---- stage the pixel tile: LDS dword j of row r = image bytes x = (ox - 5 + 4j) .. +3 of row (oy - 4 + r),
+    // assembled from two aligned global dwords with v_alignbyte (the tile origin is not dword aligned)
+    {
+        const int gx0 = ox - 5;                 // >= 17 (edge >= 22)
+        const int sh = gx0 & 3, a0 = gx0 >> 2;
+        const int max_dw = lv.pitch / 4 - 1;
+        for (int i = tid; i < FP_H * (FP_PITCH / 4); i += FAST_THREADS) {
+            const int r = i / (FP_PITCH / 4), j = i - r * (FP_PITCH / 4);
+            const int gy = min(oy - 4 + r, lv.h - 1);
+            const uint32_t* row = reinterpret_cast<const uint32_t*>(img + (size_t)gy * lv.pitch);
+            const uint32_t lo = row[min(a0 + j, max_dw)], hi = row[min(a0 + j + 1, max_dw)];
+            s_pix[i] = __builtin_amdgcn_alignbyte(hi, lo, sh);
+        }
     }
     __syncthreads();
-    const uint8_t* pix = reinterpret_cast<const uint8_t*>(s_pix) + xo; // pix[r*FP_PITCH + c], (r,c) relative to (py0,px0)
+    if (od.ablate == 1) return;
     const int thr = od.fast_thr;
-    // score region: (sx,sy) in [0,FS_W)x[0,FS_H) <-> pixel (ox-1+sx, oy-1+sy) <-> tile coords (sx+3, sy+3)
-    const int lim_x = min(FS_W, lv.roi_x0 + lv.roi_w + 1 - (ox - 1)); // scores only needed up to ROI+1
+    // score (sx, sy) <-> image pixel (ox - 1 + sx, oy - 1 + sy) <-> LDS byte (sy + 3) * FP_PITCH + sx + 4
+    const int lim_x = min(FS_W, lv.roi_x0 + lv.roi_w + 1 - (ox - 1)); // scores only needed up to ROI + 1
     const int lim_y = min(FS_H, lv.roi_y0 + lv.roi_h + 1 - (oy - 1));
-    // ---- phase 1: high-speed rejection (an arc of 9 contains ring pixel 0 or 8, and 4 or 12)
-    for (int i0 = 0; i0 < FS_H * FS_W; i0 += FAST_THREADS) {
-        int i = i0 + tid;
-        bool pass = false;
-        if (i < FS_H * FS_W) {
-            int sy = i / FS_W, sx = i % FS_W;
-            if (sx < lim_x && sy < lim_y) {
-                const uint8_t* p = pix + (sy + 3) * FP_PITCH + (sx + 3);
-                int v = p[0];
-                int d0 = v - p[ring_ofs(0)], d8 = v - p[ring_ofs(8)];
-                bool a = (abs(d0) > thr) | (abs(d8) > thr);
-                int d4 = v - p[ring_ofs(4)], d12 = v - p[ring_ofs(12)];
-                bool c = (abs(d4) > thr) | (abs(d12) > thr);
-                pass = a & c;
+    // ---- phase 1: high-speed rejection on 4 pixels per lane from 5 dword reads
+    // (an arc of 9 contains ring pixel 0 or 8, and 4 or 12)
+    {
+        const int g = tid & 31, ry = tid >> 5;
+#pragma unroll
+        for (int m = 0; m < FS_H / 8; m++) {
+            const int sy = ry + 8 * m;
+            uint32_t pm = 0; // pass mask of this lane's 4 pixels
+            if (sy < lim_y && 4 * g < lim_x) {
+                const uint32_t* rowp = s_pix + (sy + 3) * (FP_PITCH / 4) + g;
+                const uint32_t Lw = rowp[0], Cw = rowp[1], Rw = rowp[2];
+                const uint32_t Tw = rowp[1 - 3 * (FP_PITCH / 4)], Bw = rowp[1 + 3 * (FP_PITCH / 4)];
+                const uint32_t P4 = __builtin_amdgcn_alignbyte(Rw, Cw, 3);   // pixels at x + 3
+                const uint32_t P12 = __builtin_amdgcn_alignbyte(Cw, Lw, 1);  // pixels at x - 3
+                pm = 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    // an arc of 9 equal-polarity ring pixels contains pixel 0 or 8 AND pixel 4 or 12 of that polarity
+                    const int v = (int)byte_of(Cw, k);
+                    const int d0 = v - (int)byte_of(Bw, k), d8 = v - (int)byte_of(Tw, k);
+                    const int d4 = v - (int)byte_of(P4, k), d12 = v - (int)byte_of(P12, k);
+                    const bool dark = ((d0 > thr) | (d8 > thr)) & ((d4 > thr) | (d12 > thr));
+                    const bool brig = ((d0 < -thr) | (d8 < -thr)) & ((d4 < -thr) | (d12 < -thr));
+                    pm |= (uint32_t)((dark | brig) && (4 * g + k < lim_x)) << k;
+                }
+            }
+            // wave-level compaction: one LDS atomic per wave and row group, positions from ballots
+            int base = 0;
+            unsigned long long bal[4];
+            int tot = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) { bal[k] = __ballot((pm >> k) & 1u); tot += __popcll(bal[k]); }
+            if (tot) {
+                if ((tid & 63) == 0) base = atomicAdd(&s_n1, tot);
+                base = __shfl(base, 0);
+                const unsigned long long below = (1ull << (tid & 63)) - 1ull;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    if ((pm >> k) & 1u) s_list[base + __popcll(bal[k] & below)] = (uint16_t)(sy * FS_W + 4 * g + k);
+                    base += __popcll(bal[k]);
+                }
             }
         }
-        unsigned long long bal = __ballot(pass);
-        int base = 0;
-        if ((tid & 63) == 0 && bal) base = atomicAdd(&s_n1, __popcll(bal));
-        base = __shfl(base, 0);
-        if (pass) s_list[base + __popcll(bal & ((1ull << (tid & 63)) - 1ull))] = (uint16_t)i;
     }
     __syncthreads();
+    if (od.ablate == 2) return;
+    const uint8_t* pix = reinterpret_cast<const uint8_t*>(s_pix);
     // ---- phase 2: segment test + exact score for the survivors (dense lanes)
     const int n1 = s_n1;
     for (int j = tid; j < n1; j += FAST_THREADS) {
-        int i = s_list[j];
-        int sy = i / FS_W, sx = i % FS_W;
-        const uint8_t* p = pix + (sy + 3) * FP_PITCH + (sx + 3);
-        int v = p[0];
+        const int i = s_list[j];
+        const int sy = i / FS_W, sx = i % FS_W;
+        const uint8_t* p = pix + (sy + 3) * FP_PITCH + (sx + 4);
+        const int v = p[0];
         int d[16];
         uint32_t mb = 0, md = 0; // ring brighter than v+thr / darker than v-thr
 #pragma unroll
@@ -260,24 +293,24 @@ void fast_nms_k(OrbDev od)
         mb |= mb << 16; md |= md << 16;
         uint32_t rb = mb & (mb >> 1); rb &= rb >> 2; rb &= rb >> 4; rb &= mb >> 8; // 9 contiguous
         uint32_t rd = md & (md >> 1); rd &= rd >> 2; rd &= rd >> 4; rd &= md >> 8;
-        if (((rb | rd) & 0xFFFFu) != 0) s_score[sy * FS_W + sx] = (uint8_t)fast_exact_score(d);
+        if (((rb | rd) & 0xFFFFu) != 0) s_score[i] = (uint8_t)fast_exact_score(d);
     }
     __syncthreads();
+    if (od.ablate == 3) return;
     // ---- phase 3: 3x3 non-max suppression on the score tile, outputs inside the ROI only
     const int out_w = min(FT_W, lv.roi_x0 + lv.roi_w - ox), out_h = min(FT_H, lv.roi_y0 + lv.roi_h - oy);
     for (int j = tid; j < n1; j += FAST_THREADS) {
-        int i = s_list[j];
-        int sy = i / FS_W, sx = i % FS_W;
-        int s = s_score[i];
-        if (s == 0 || sx < 1 || sy < 1 || sx > out_w || sy > out_h) continue;
+        const int i = s_list[j];
+        const int sy = i / FS_W, sx = i % FS_W;
+        const int sc = s_score[i];
+        if (sc == 0 || sx < 1 || sy < 1 || sx > out_w || sy > out_h) continue;
         const uint8_t* c = s_score + i;
-        bool mx = s > c[-1] && s > c[1] && s > c[-FS_W - 1] && s > c[-FS_W] && s > c[-FS_W + 1] &&
-                  s > c[FS_W - 1] && s > c[FS_W] && s > c[FS_W + 1];
+        const bool mx = sc > c[-1] && sc > c[1] && sc > c[-FS_W - 1] && sc > c[-FS_W] && sc > c[-FS_W + 1] &&
+                        sc > c[FS_W - 1] && sc > c[FS_W] && sc > c[FS_W + 1];
         if (mx) {
-            int e = atomicAdd(&s_ne, 1);
-            int gx = ox - 1 + sx, gy = oy - 1 + sy;
-            s_emit[e] = ((uint32_t)s << 24) | ((uint32_t)gy << 12) | (uint32_t)gx;
-            atomicAdd(&od.hist[((size_t)b * od.L + l) * 256 + s], 1u);
+            const int e = atomicAdd(&s_ne, 1);
+            const int gx = ox - 1 + sx, gy = oy - 1 + sy;
+            s_emit[e] = ((uint32_t)sc << 24) | ((uint32_t)gy << 12) | (uint32_t)gx;
         }
     }
     __syncthreads();
@@ -344,8 +377,11 @@ void select_k(OrbDev od)
     const bool harris = od.score_type == 0;
     const int n1 = harris ? 2 * nf : nf; // first retainBest budget (by FAST score)
 
-    if (tid < 256) s_hist[tid] = od.hist[((size_t)b * od.L + l) * 256 + tid];
+    // FAST score histogram of this (frame, level) from its candidate list
+    if (tid < 256) s_hist[tid] = 0;
     if (tid == 0) { s_nA = 0; s_nS = 0; }
+    __syncthreads();
+    for (int i = tid; i < ncand; i += SEL_THREADS) atomicAdd(&s_hist[cand[i] >> 24], 1u);
     __syncthreads();
     if (tid == 0) {
         // retainBest(n1) as a set: keep score s iff #(score > s) < n1; n1 == 0 clears
@@ -430,7 +466,9 @@ void select_k(OrbDev od)
 // ---------------------------------------------------------------- K4-K6: describe
 constexpr int DP_R = 21;               // raw patch radius: 18 (pattern reach) + 3 (blur)
 constexpr int DP_N = 2 * DP_R + 1;     // 43
-constexpr int DP_PITCH = 48;           // LDS bytes per raw row (12 dwords)
+constexpr int DP_PITCH = 52;           // LDS bytes per raw row (13 dwords: odd, so a column of rows is bank-conflict free)
+constexpr int DP_ROW_DW = 12;          // dwords actually loaded per row (45 bytes + misalignment)
+constexpr int HB_PITCH = 42;           // u16 per row of the horizontally blurred patch (21 dwords: odd)
 constexpr int DB_N = 37;               // blurred patch side (radius 18)
 constexpr int DB_PITCH = 40;
 constexpr int DESC_WAVES = 4;
@@ -465,7 +503,7 @@ __global__ __launch_bounds__(64 * DESC_WAVES)
 void describe_k(OrbDev od, DescArgs out)
 {
     __shared__ uint32_t s_raw[DESC_WAVES][DP_N * DP_PITCH / 4];
-    __shared__ uint16_t s_h[DESC_WAVES][DP_N * DB_PITCH];
+    __shared__ uint16_t s_h[DESC_WAVES][DP_N * HB_PITCH];
     __shared__ uint8_t s_blur[DESC_WAVES][DB_N * DB_PITCH];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int b = blockIdx.y;
@@ -494,26 +532,28 @@ void describe_k(OrbDev od, DescArgs out)
     const int xa = px0 & ~3, xo = px0 & 3;
     const int max_dw = lv.pitch / 4 - 1;
     uint32_t* raw32 = s_raw[wave];
-    for (int i = lane; i < DP_N * (DP_PITCH / 4); i += 64) {
-        int r = i / (DP_PITCH / 4), c = i % (DP_PITCH / 4);
-        raw32[i] = active ? reinterpret_cast<const uint32_t*>(img + (size_t)(py0 + r) * lv.pitch)[min(xa / 4 + c, max_dw)] : 0u;
+    for (int i = lane; i < DP_N * DP_ROW_DW; i += 64) {
+        int r = i / DP_ROW_DW, c = i % DP_ROW_DW;
+        raw32[r * (DP_PITCH / 4) + c] = active ? reinterpret_cast<const uint32_t*>(img + (size_t)(py0 + r) * lv.pitch)[min(xa / 4 + c, max_dw)] : 0u;
     }
     __syncthreads();
     const uint8_t* raw = reinterpret_cast<const uint8_t*>(raw32) + xo; // raw[r*DP_PITCH + c], centre at (21,21)
-    // ---- IC_Angle: lane v+15 sums row v of the circular patch
+    // ---- IC_Angle: lane (v + 15) * 2 + half sums one half of row v of the circular patch (integer sums: any order)
     int m10 = 0, m01 = 0;
-    if (lane < 31) {
-        int v = lane - 15;
-        int dmax = c_umax[abs(v)];
+    if (lane < 62) {
+        const int v = (lane >> 1) - 15, half = lane & 1;
+        const int dmax = c_umax[abs(v)];
         const uint8_t* row = raw + (DP_R + v) * DP_PITCH + DP_R;
         int rs = 0;
-        for (int u = -dmax; u <= dmax; u++) { int val = row[u]; m10 += u * val; rs += val; }
+        const int u0 = half ? 1 : -dmax, u1 = half ? dmax : 0;
+        for (int u = u0; u <= u1; u++) { const int val = row[u]; m10 += u * val; rs += val; }
         m01 = v * rs;
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { m10 += __shfl_xor(m10, o); m01 += __shfl_xor(m01, o); }
     const float angle = fast_atan2_deg((float)m01, (float)m10);
-    // ---- separable 7x7 Gaussian of the patch: rows (43 x 37) then columns (37 x 37)
+    // ---- separable 7x7 Gaussian of the patch: rows (43 x 37) then columns (37 x 37).  One output per lane and
+    // step: measured faster than longer per-lane runs (the kernel is VALU-bound, not LDS-bound).
     uint16_t* hbuf = s_h[wave];
     for (int i = lane; i < DP_N * DB_N; i += 64) {
         int r = i / DB_N, c = i % DB_N; // output column c <-> raw column c+3 (centre), taps c..c+6
@@ -521,7 +561,7 @@ void describe_k(OrbDev od, DescArgs out)
         int acc = 0;
 #pragma unroll
         for (int j = 0; j < 7; j++) acc += c_gk[j] * p[j];
-        hbuf[r * DB_PITCH + c] = (uint16_t)acc; // <= 257*255 = 65535
+        hbuf[r * HB_PITCH + c] = (uint16_t)acc; // <= 257*255 = 65535
     }
     __syncthreads();
     uint8_t* blur = s_blur[wave];
@@ -529,7 +569,7 @@ void describe_k(OrbDev od, DescArgs out)
         int r = i / DB_N, c = i % DB_N;
         int acc = 0;
 #pragma unroll
-        for (int j = 0; j < 7; j++) acc += c_gk[j] * (int)hbuf[(r + j) * DB_PITCH + c];
+        for (int j = 0; j < 7; j++) acc += c_gk[j] * (int)hbuf[(r + j) * HB_PITCH + c];
         int v = (acc + (1 << 15)) >> 16;
         blur[r * DB_PITCH + c] = (uint8_t)(v > 255 ? 255 : v);
     }
@@ -609,7 +649,7 @@ struct OrbPlan {
     int level0_pitch = 0;
     long long level0_fstride = 0;
     uint8_t* last_l0 = nullptr; int last_l0_pitch = 0;      // level 0 of the last call (may alias caller memory)
-    uint32_t* counters = nullptr; size_t counters_bytes = 0; // hist + cnt + sel_cnt + frame_status (zeroed per batch)
+    uint32_t* counters = nullptr; size_t counters_bytes = 0; // cnt + sel_cnt + frame_status (zeroed per batch)
 };
 
 void orb_plan_destroy(mslam_ctx* ctx)
@@ -649,6 +689,7 @@ static int orb_plan_get(mslam_ctx* ctx, int w, int h, int B, int channels, const
     od.L = p->nlevels; od.B = B; od.edge = p->edge_threshold;
     od.max_kpts = ctx->max_kpts < SEL_LEVEL_CAP ? ctx->max_kpts : SEL_LEVEL_CAP; // per-level list capacity
     od.fast_thr = p->fast_threshold; od.score_type = p->score_type;
+    od.ablate = getenv("MSLAM_FAST_ABLATE") ? atoi(getenv("MSLAM_FAST_ABLATE")) : 0; // development only
     const int L = od.L, edge = od.edge;
     // level geometry and feature budget -- ORB::operator() / computeKeyPoints (OpenCV 2.4.13)
     const double scaleFactor = (double)p->scale_factor;
@@ -693,15 +734,14 @@ static int orb_plan_get(mslam_ctx* ctx, int w, int h, int B, int channels, const
     }
     od.tiles_per_frame = tile_base;
     const size_t off_sel = reserve(sizeof(uint2) * (size_t)B * L * od.max_kpts);
-    const size_t n_hist = (size_t)B * L * 256, n_cnt = (size_t)B * L;
-    pl->counters_bytes = sizeof(uint32_t) * (n_hist + 2 * n_cnt + B);
+    const size_t n_cnt = (size_t)B * L;
+    pl->counters_bytes = sizeof(uint32_t) * (2 * n_cnt + B);
     const size_t off_cnt = reserve(pl->counters_bytes);
     HIP_TRY(ctx, hipMalloc(&pl->arena, bytes));
     pl->arena_bytes = bytes;
     char* base = (char*)pl->arena;
     pl->counters = (uint32_t*)(base + off_cnt);
-    od.hist = pl->counters;
-    od.cnt = od.hist + n_hist;
+    od.cnt = pl->counters;
     od.sel_cnt = (int32_t*)(od.cnt + n_cnt);
     od.frame_status = od.sel_cnt + n_cnt;
     od.sel = (uint2*)(base + off_sel);
