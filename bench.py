@@ -96,6 +96,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="independent streams per GPU per step")
     ap.add_argument("--cpu-frames", type=int, default=24, help="frames of the cpu_baseline sample (0 = skip)")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip the second, event-instrumented pass")
+    ap.add_argument("--overlap", type=int, default=1, help="1: PnP chain on a second context/stream, overlapping extract+match")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -106,18 +107,27 @@ def main():
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
         args.gpus = world
     dist = None
+    # rehearsal knobs (never set by the driver): run several ranks on one GPU over gloo to exercise the N > 1 code path
+    backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
+    if "BENCH_FORCE_DEVICE" in os.environ:
+        local_rank = int(os.environ["BENCH_FORCE_DEVICE"])
     if world > 1:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
+    tdev = "cuda" if backend == "nccl" else "cpu"
 
     from monocular_slam_amd import api
     from monocular_slam_amd.tracking import TrackingBatch
 
     B = args.batch
     ctx = api.Context(local_rank, W, H, 4096, B)
-    tb = TrackingBatch(ctx, B, W, H, NFEAT, cap=NFEAT + 1024, ratio=0.8, pnp_points=PNP_P, pnp_hyps=PNP_H)
+    ctx2 = api.Context(local_rank, W, H, 4096, B) if args.overlap else None
+    tb = TrackingBatch(ctx, B, W, H, NFEAT, cap=NFEAT + 1024, ratio=0.8, pnp_points=PNP_P, pnp_hyps=PNP_H, pnp_ctx=ctx2)
     frames = make_frames(B, 5005 + 1000 * rank)
     tb.upload_frames(frames)
     pnp = make_pnp(B, 3003 + 1000 * rank)
@@ -126,11 +136,12 @@ def main():
     tb.set_pnp_problems(*pnp[:5], pp)
 
     def barrier():
-        ctx.sync()
+        tb.sync()
         if dist is not None:
             import torch
             dist.barrier()
-            torch.cuda.synchronize()
+            if tdev == "cuda":
+                torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         tb.step()
@@ -142,7 +153,7 @@ def main():
     elapsed = time.perf_counter() - t0
     if dist is not None:
         import torch
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=tdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -153,11 +164,13 @@ def main():
     # context's stream -> per-kernel average duration for the roofline of the dominant kernel
     kern = {}
     if not args.no_kernel_events:
-        ctx.profile_enable(64 * args.steps)
+        for c in {ctx, tb.pnp_ctx}:
+            c.profile_enable(64 * args.steps)
         for _ in range(args.steps):
             tb.step()
-        kern = ctx.profile_read()
-        ctx.profile_enable(0)
+        for c in {ctx, tb.pnp_ctx}:
+            kern.update(c.profile_read())
+            c.profile_enable(0)
 
     if rank == 0:
         frames_total = world * B * args.steps

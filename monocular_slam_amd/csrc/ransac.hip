@@ -915,12 +915,31 @@ __device__ __forceinline__ void pnp_score_body(const PnpArgs& a, int b, int h0, 
             int cnt = 0;
 #pragma unroll
             for (int j = 0; j < PNP_PT; j++) {
-                double u, v;
-                project_pt(Rt, fx, fy, cx, cy, k, HAS_DIST, X[j], Y[j], Z[j], u, v);
-                const double dx = ox[j] - u, dy = oy[j] - v;
-                // sqrt(d2) < thr  <=>  d2 < thr2cut  (thr2cut = smallest double whose sqrt is >= thr)
-                const bool in = live[j] && (dx * dx + dy * dy < a.thr2cut);
-                cnt += __popcll(__ballot(in));
+                if (HAS_DIST) {
+                    double u, v;
+                    project_pt(Rt, fx, fy, cx, cy, k, true, X[j], Y[j], Z[j], u, v);
+                    const double dx = ox[j] - u, dy = oy[j] - v;
+                    // sqrt(d2) < thr  <=>  d2 < thr2cut  (thr2cut = smallest double whose sqrt is >= thr)
+                    const bool in = live[j] && (dx * dx + dy * dy < a.thr2cut);
+                    cnt += __popcll(__ballot(in));
+                } else {
+                    // Without distortion an inlier needs |fx*px - (ox-cx)*pz| < thr*|pz| (and the same in y).  This
+                    // division-free band test (with a 1e-6 relative safety margin: a strict superset of the exact
+                    // rule) rejects almost every point of a wrong hypothesis; only when some lane of the wavefront
+                    // passes is the exact cvProjectPoints2 evaluation (same operations as project_pt) carried out.
+                    const double px = Rt[0] * X[j] + Rt[1] * Y[j] + Rt[2] * Z[j] + Rt[3];
+                    const double py = Rt[4] * X[j] + Rt[5] * Y[j] + Rt[6] * Z[j] + Rt[7];
+                    const double pz = Rt[8] * X[j] + Rt[9] * Y[j] + Rt[10] * Z[j] + Rt[11];
+                    const double band = a.thr * (1.0 + 1e-6) * fabs(pz);
+                    const bool maybe = live[j] && ((pz == 0.0) | ((fabs(fx * px - (ox[j] - cx) * pz) <= band) & (fabs(fy * py - (oy[j] - cy) * pz) <= band)));
+                    if (__ballot(maybe)) { // wave-uniform
+                        double z = pz ? 1. / pz : 1;
+                        const double u = (px * z) * fx + cx, v = (py * z) * fy + cy;
+                        const double dx = ox[j] - u, dy = oy[j] - v;
+                        const bool in = maybe && (dx * dx + dy * dy < a.thr2cut);
+                        cnt += __popcll(__ballot(in));
+                    }
+                }
             }
             if (lane == 0) atomicAdd(&s_cnt[q], cnt);
         }

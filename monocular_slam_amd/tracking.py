@@ -17,8 +17,11 @@ from . import api
 
 class TrackingBatch:
     def __init__(self, ctx: api.Context, B: int, w: int, h: int, nfeatures: int, cap: int | None = None,
-                 ratio: float = 0.8, pnp_points: int = 0, pnp_hyps: int = 0):
+                 ratio: float = 0.8, pnp_points: int = 0, pnp_hyps: int = 0, pnp_ctx: api.Context | None = None):
         self.ctx, self.B, self.w, self.h = ctx, B, w, h
+        # optional second context (= second HIP stream on the same GPU) for the PnP chain, so that it overlaps the
+        # extract+match chain of the same step (software pipelining across stages; outputs are unchanged)
+        self.pnp_ctx = pnp_ctx or ctx
         self.params = api.default_orb_params(nfeatures)
         self.cap = cap or min(ctx.max_kpts, nfeatures + 1024)
         self.ratio = ratio
@@ -47,7 +50,7 @@ class TrackingBatch:
         """B synthetic 3D-2D problems resident on the device (config C2 shape)."""
         B, P, H = self.B, self.pnp["P"], self.pnp["H"]
         D = api.DevBuf.from_array
-        ctx = self.ctx
+        ctx = self.pnp_ctx
         self.pnp.update(
             X=D(ctx, X), x=D(ctx, x), K=D(ctx, K), dist=D(ctx, dist), samples=D(ctx, samples),
             Pn=D(ctx, np.full(B, P, np.int32)), params=params,
@@ -68,7 +71,7 @@ class TrackingBatch:
 
     def pnp_ransac(self):
         q = self.pnp
-        self.ctx.pnp_ransac_batch_dev(q["X"].ptr, q["x"].ptr, q["Pn"].ptr, q["P"], q["K"].ptr, q["dist"].ptr,
+        self.pnp_ctx.pnp_ransac_batch_dev(q["X"].ptr, q["x"].ptr, q["Pn"].ptr, q["P"], q["K"].ptr, q["dist"].ptr,
                                       q["samples"].ptr, q["H"], self.B, q["params"], q["Rt"].ptr, q["rvec"].ptr,
                                       q["tvec"].ptr, q["inl"].ptr, q["counts"].ptr, q["best"].ptr, q["ninl"].ptr)
 
@@ -80,9 +83,14 @@ class TrackingBatch:
             self.pnp_ransac()
         self.cur = 1 - self.cur
 
+    def sync(self):
+        self.ctx.sync()
+        if self.pnp_ctx is not self.ctx:
+            self.pnp_ctx.sync()
+
     def results(self):
         """Host copies of the last step's outputs (syncs)."""
-        self.ctx.sync()
+        self.sync()
         p = 1 - self.cur  # buffers written by the last step
         B, cap = self.B, self.cap
         out = dict(n=self.n[p].download(np.int32, (B,)), status=self.status.download(np.int32, (B,)),
