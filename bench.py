@@ -196,8 +196,10 @@ def main():
             traffic = None
             pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
             if os.path.exists(pmc_path):
-                try:
-                    traffic = json.load(open(pmc_path)).get(dom, {}).get("hbm_bytes_per_launch")
+                try:  # PMC passes were collected at the default batch: only comparable per launch at that batch
+                    pmc = json.load(open(pmc_path))
+                    if int(pmc.get("_batch", 32)) == B and world == 1:
+                        traffic = pmc.get(dom, {}).get("hbm_bytes_per_launch")
                 except Exception:
                     traffic = None
             out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
