@@ -144,6 +144,62 @@ __device__ void jacobi_mem(double* a, int n, double* d, double* v)
     }
 }
 
+// The same cyclic Jacobi executed by a whole workgroup on matrices in LDS: every thread evaluates the (identical)
+// rotation parameters, lanes 0..n-1 rotate the matrix entries and lanes n..2n-1 the eigenvector rows of one (p,q)
+// step.  Element for element the arithmetic equals jacobi_mem / the oracle's routine.  All threads must call it.
+__device__ void jacobi_block(double* a, int n, double* d, double* v, double* bb, double* z, int tid)
+{
+    for (int i = tid; i < n * n; i += blockDim.x) v[i] = (i / n == i % n) ? 1.0 : 0.0;
+    if (tid < n) { d[tid] = bb[tid] = a[tid * n + tid]; z[tid] = 0.0; }
+    __syncthreads();
+    for (int sweep = 1; sweep <= 60; sweep++) {
+        double sm = 0.0;
+        for (int p = 0; p < n - 1; p++)
+            for (int q = p + 1; q < n; q++) sm += fabs(a[p * n + q]);
+        if (sm == 0.0) break; // uniform: every thread read the same values
+        const double tresh = sweep < 4 ? 0.2 * sm / (n * n) : 0.0;
+        for (int p = 0; p < n - 1; p++)
+            for (int q = p + 1; q < n; q++) {
+                const double apq = a[p * n + q], dp = d[p], dq = d[q];
+                const double g = 100.0 * fabs(apq);
+                const bool kill = sweep > 4 && fabs(dp) + g == fabs(dp) && fabs(dq) + g == fabs(dq);
+                const bool rot = !kill && fabs(apq) > tresh;
+                if (!kill && !rot) continue; // uniform
+                double s_ = 0.0, tau = 0.0, h = 0.0;
+                if (rot) {
+                    double hh = dq - dp, t;
+                    if (fabs(hh) + g == fabs(hh)) t = apq / hh;
+                    else {
+                        const double theta = 0.5 * hh / apq;
+                        t = 1.0 / (fabs(theta) + sqrt(1.0 + theta * theta));
+                        if (theta < 0.0) t = -t;
+                    }
+                    const double c = 1.0 / sqrt(1.0 + t * t);
+                    s_ = t * c; tau = s_ / (1.0 + c); h = t * apq;
+                }
+                __syncthreads(); // everyone has read a[p][q], d[p], d[q]
+                if (tid == 0) {
+                    if (rot) { z[p] -= h; z[q] += h; d[p] -= h; d[q] += h; }
+                    a[p * n + q] = 0.0;
+                }
+                if (rot && tid < n && tid != p && tid != q) {
+                    const int j = tid;
+                    double* px = j < p ? &a[j * n + p] : &a[p * n + j];
+                    double* py = j < q ? &a[j * n + q] : &a[q * n + j];
+                    const double x = *px, y = *py;
+                    *px = x - s_ * (y + x * tau); *py = y + s_ * (x - y * tau);
+                } else if (rot && tid >= n && tid < 2 * n) {
+                    const int j = tid - n;
+                    const double x = v[j * n + p], y = v[j * n + q];
+                    v[j * n + p] = x - s_ * (y + x * tau); v[j * n + q] = y + s_ * (x - y * tau);
+                }
+                __syncthreads();
+            }
+        if (tid < n) { bb[tid] += z[tid]; d[tid] = bb[tid]; z[tid] = 0.0; }
+        __syncthreads();
+    }
+}
+
 // index of the smallest eigenvalue, first index on ties (== column 0 after the stable ascending sort)
 __device__ __forceinline__ int argmin_first(const double* d, int n)
 {
@@ -175,79 +231,66 @@ __device__ void rank2(double* F)
     }
 }
 
-// Null vector of an 8x9 system: Gauss-Jordan with complete pivoting, everything in registers
-// (fully unrolled; dynamic pivot positions are handled with selects, never with indexed arrays).
-__device__ void null_8x9(double (&A)[8][9], double* f)
+// Null vector of an 8x9 system: Gauss-Jordan with complete pivoting (same pivot order and arithmetic as the CPU
+// restatement).  The 72 doubles of a lane live in LDS, element-major (s[(r*9+c)*64 + lane]): pivot positions differ
+// from lane to lane, so the matrix is indexed dynamically -- in registers that costs a select chain per access
+// (measured 6x slower); ds_read_b64 at [element][lane] is bank-conflict free whatever the element.
+__device__ void null_8x9(double* __restrict__ s, int lane, double* f)
 {
+#define A_(r, c) s[((r) * 9 + (c)) * 64 + lane]
     unsigned used_r = 0, used_c = 0;
     int prow[8], pcol[8];
     bool ok = true;
-#pragma unroll
     for (int k = 0; k < 8; k++) {
         double best = -1.0;
         int br = 0, bc = 0;
-#pragma unroll
-        for (int r = 0; r < 8; r++)
-#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            if ((used_r >> r) & 1u) continue;
             for (int c = 0; c < 9; c++) {
-                double v = fabs(A[r][c]);
-                bool take = !((used_r >> r) & 1u) && !((used_c >> c) & 1u) && v > best;
-                best = take ? v : best; br = take ? r : br; bc = take ? c : bc;
+                if ((used_c >> c) & 1u) continue;
+                const double v = fabs(A_(r, c));
+                if (v > best) { best = v; br = r; bc = c; }
             }
+        }
         used_r |= 1u << br; used_c |= 1u << bc; prow[k] = br; pcol[k] = bc;
+        const double pv = A_(br, bc);
+        if (pv == 0.0) { ok = false; break; }
         double piv[9];
 #pragma unroll
-        for (int c = 0; c < 9; c++) {
-            double v = A[0][c];
-#pragma unroll
-            for (int r = 1; r < 8; r++) v = (r == br) ? A[r][c] : v;
-            piv[c] = v;
-        }
-        double pv = piv[0];
-#pragma unroll
-        for (int c = 1; c < 9; c++) pv = (c == bc) ? piv[c] : pv;
-        if (pv == 0.0) ok = false;
-#pragma unroll
+        for (int c = 0; c < 9; c++) piv[c] = A_(br, c);
         for (int r = 0; r < 8; r++) {
-            double arc = A[r][0];
-#pragma unroll
-            for (int c = 1; c < 9; c++) arc = (c == bc) ? A[r][c] : arc;
-            double m = arc / pv;
-            bool upd = (r != br);
+            if (r == br) continue;
+            const double m = A_(r, bc) / pv;
 #pragma unroll
             for (int c = 0; c < 9; c++) {
-                double nv = (c == bc) ? 0.0 : A[r][c] - m * piv[c];
-                A[r][c] = upd ? nv : A[r][c];
+                const double nv = A_(r, c) - m * piv[c];
+                A_(r, c) = (c == bc) ? 0.0 : nv;
             }
         }
     }
-    int cf = 0;
-#pragma unroll
-    for (int c = 0; c < 9; c++) cf = ((used_c >> c) & 1u) ? cf : c;
     double fv[9];
 #pragma unroll
-    for (int c = 0; c < 9; c++) fv[c] = (c == cf) ? 1.0 : 0.0;
+    for (int c = 0; c < 9; c++) fv[c] = 0.0;
+    if (ok) {
+        int cf = 0;
+        for (int c = 0; c < 9; c++) if (!((used_c >> c) & 1u)) cf = c;
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
-        double num = 0.0, den = 1.0;
+        for (int c = 0; c < 9; c++) fv[c] = (c == cf) ? 1.0 : 0.0;
+        for (int k = 0; k < 8; k++) {
+            const double val = -A_(prow[k], cf) / A_(prow[k], pcol[k]);
 #pragma unroll
-        for (int r = 0; r < 8; r++)
+            for (int c = 0; c < 9; c++) fv[c] = (c == pcol[k]) ? val : fv[c];
+        }
+        double nn = 0.0;
 #pragma unroll
-            for (int c = 0; c < 9; c++) {
-                bool isr = (r == prow[k]);
-                num = (isr && c == cf) ? A[r][c] : num;
-                den = (isr && c == pcol[k]) ? A[r][c] : den;
-            }
-        double val = -num / den;
+        for (int c = 0; c < 9; c++) nn += fv[c] * fv[c];
+        nn = sqrt(nn);
 #pragma unroll
-        for (int c = 0; c < 9; c++) fv[c] = (c == pcol[k]) ? val : fv[c];
+        for (int c = 0; c < 9; c++) fv[c] = fv[c] / nn;
     }
-    double nn = 0.0;
 #pragma unroll
-    for (int c = 0; c < 9; c++) nn += fv[c] * fv[c];
-    nn = sqrt(nn);
-#pragma unroll
-    for (int c = 0; c < 9; c++) f[c] = ok ? fv[c] / nn : 0.0;
+    for (int c = 0; c < 9; c++) f[c] = fv[c];
+#undef A_
 }
 
 // ------------------------------------------------------------------ fundamental matrix
@@ -304,7 +347,8 @@ void fmat_solve_k(FmatArgs a)
     const double* x1 = a.x1 + (size_t)b * a.capM * 2;
     const double* x2 = a.x2 + (size_t)b * a.capM * 2;
     const int32_t* s = a.samples + ((size_t)b * a.H + h) * 8;
-    double A[8][9];
+    __shared__ double s_A[72 * 64];
+    const int lane = threadIdx.x;
     bool valid = M >= 8 && maxt > 0.0;
 #pragma unroll
     for (int k = 0; k < 8; k++) {
@@ -312,12 +356,13 @@ void fmat_solve_k(FmatArgs a)
         if (i < 0 || i >= M) { valid = false; i = 0; }
         float u1 = (float)(x1[2 * i] / maxt), v1 = (float)(x1[2 * i + 1] / maxt);
         float u2 = (float)(x2[2 * i] / maxt), v2 = (float)(x2[2 * i + 1] / maxt);
-        A[k][0] = (double)(u2 * u1); A[k][1] = (double)(u2 * v1); A[k][2] = (double)u2;
-        A[k][3] = (double)(v2 * u1); A[k][4] = (double)(v2 * v1); A[k][5] = (double)v2;
-        A[k][6] = (double)u1; A[k][7] = (double)v1; A[k][8] = 1.0;
+        const double row[9] = { (double)(u2 * u1), (double)(u2 * v1), (double)u2, (double)(v2 * u1), (double)(v2 * v1), (double)v2,
+                                (double)u1, (double)v1, 1.0 };
+#pragma unroll
+        for (int c = 0; c < 9; c++) s_A[(k * 9 + c) * 64 + lane] = row[c];
     }
     double F[9];
-    null_8x9(A, F);
+    null_8x9(s_A, lane, F);
     rank2(F);
     double* ms = a.models_s + ((size_t)b * a.H + h) * 9;
     double* mo = a.models + ((size_t)b * a.H + h) * 9;
@@ -358,39 +403,75 @@ __device__ __forceinline__ bool fmat_inlier(const double* F, double u1, double v
     return (double)(float)(e1 > e2 ? e1 : e2) <= thr; // err is stored as float by OpenCV
 }
 
+// Scoring (same structure as pnp_score_k): a workgroup owns FM_HPB hypotheses (F staged in LDS), each lane keeps
+// FM_PT point pairs in registers.  For metric 1 a division-free band test (d^2 <= thr'*(a^2+b^2) on both epipolar
+// lines, thr' = thr*(1+1e-5): a strict superset of the exact rule) skips the two f64 divisions of OpenCV's error
+// measure unless some lane of the wavefront can be an inlier.
+constexpr int FM_HPB = 32;
+constexpr int FM_PT = 8;
+
 __global__ __launch_bounds__(SCORE_THREADS)
 void fmat_score_k(FmatArgs a)
 {
-    const int b = blockIdx.y, h0 = blockIdx.x * HT, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.y, h0 = blockIdx.x * FM_HPB, tid = threadIdx.x, lane = tid & 63;
+    const int nh = min(FM_HPB, a.H - h0);
     const int M = a.M[b];
-    __shared__ double s_F[HT][9];
-    __shared__ int s_cnt[HT];
-    if (tid < HT * 9) {
-        int hh = tid / 9, e = tid % 9;
-        s_F[hh][e] = (h0 + hh < a.H) ? a.models[((size_t)b * a.H + h0 + hh) * 9 + e] : 0.0;
+    __shared__ double s_F[FM_HPB][9];
+    __shared__ int s_cnt[FM_HPB];
+    for (int i = tid; i < FM_HPB * 9; i += SCORE_THREADS) {
+        const int hh = i / 9, e = i % 9;
+        s_F[hh][e] = (hh < nh) ? a.models[((size_t)b * a.H + h0 + hh) * 9 + e] : 0.0;
     }
-    if (tid < HT) s_cnt[tid] = 0;
+    if (tid < FM_HPB) s_cnt[tid] = 0;
     __syncthreads();
-    int cnt[HT];
-#pragma unroll
-    for (int k = 0; k < HT; k++) cnt[k] = 0;
     const double4* pts = reinterpret_cast<const double4*>(a.pts + (size_t)b * a.capM * 4);
-    for (int i0 = 0; i0 < M; i0 += SCORE_THREADS) {
-        const int i = i0 + tid;
-        const bool live = i < M;
-        double4 p = live ? pts[i] : make_double4(0, 0, 0, 0);
+    const double thr_band = a.thr * (1.0 + 1e-5);
+    for (int c0 = 0; c0 < M; c0 += SCORE_THREADS * FM_PT) {
+        double u1[FM_PT], v1[FM_PT], u2[FM_PT], v2[FM_PT];
+        bool live[FM_PT];
 #pragma unroll
-        for (int k = 0; k < HT; k++) {
-            bool in = live && fmat_inlier(s_F[k], p.x, p.y, p.z, p.w, a.metric, a.thr);
-            cnt[k] += __popcll(__ballot(in)); // wave-uniform
+        for (int j = 0; j < FM_PT; j++) {
+            const int i = c0 + j * SCORE_THREADS + tid;
+            live[j] = i < M;
+            const double4 p = live[j] ? pts[i] : make_double4(0, 0, 0, 0);
+            u1[j] = p.x; v1[j] = p.y; u2[j] = p.z; v2[j] = p.w;
+        }
+        for (int q = 0; q < nh; q++) {
+            double F[9];
+#pragma unroll
+            for (int e = 0; e < 9; e++) F[e] = s_F[q][e];
+            int cnt = 0;
+#pragma unroll
+            for (int j = 0; j < FM_PT; j++) {
+                if (a.metric == 0) {
+                    const bool in = live[j] && fmat_inlier(F, u1[j], v1[j], u2[j], v2[j], 0, a.thr);
+                    cnt += __popcll(__ballot(in));
+                } else {
+                    // same operations as fmat_inlier (OpenCV computeReprojError), divisions deferred behind the band test
+                    const double aa = F[0] * u1[j] + F[1] * v1[j] + F[2];
+                    const double bb = F[3] * u1[j] + F[4] * v1[j] + F[5];
+                    const double cc = F[6] * u1[j] + F[7] * v1[j] + F[8];
+                    const double n2 = aa * aa + bb * bb;
+                    const double d2 = u2[j] * aa + v2[j] * bb + cc;
+                    const double a2 = F[0] * u2[j] + F[3] * v2[j] + F[6];
+                    const double b2 = F[1] * u2[j] + F[4] * v2[j] + F[7];
+                    const double c2 = F[2] * u2[j] + F[5] * v2[j] + F[8];
+                    const double n1 = a2 * a2 + b2 * b2;
+                    const double d1 = u1[j] * a2 + v1[j] * b2 + c2;
+                    const bool maybe = live[j] && (d2 * d2 <= thr_band * n2) && (d1 * d1 <= thr_band * n1);
+                    if (__ballot(maybe)) { // wave-uniform
+                        const double s2 = 1. / n2, s1 = 1. / n1;
+                        const double e1 = d1 * d1 * s1, e2 = d2 * d2 * s2;
+                        const bool in = maybe && ((double)(float)(e1 > e2 ? e1 : e2) <= a.thr);
+                        cnt += __popcll(__ballot(in));
+                    }
+                }
+            }
+            if (lane == 0) atomicAdd(&s_cnt[q], cnt);
         }
     }
-    if (lane == 0)
-#pragma unroll
-        for (int k = 0; k < HT; k++) atomicAdd(&s_cnt[k], cnt[k]);
     __syncthreads();
-    if (tid < HT && h0 + tid < a.H) a.counts[(size_t)b * a.H + h0 + tid] = s_cnt[tid];
-    (void)wave;
+    if (tid < nh) a.counts[(size_t)b * a.H + h0 + tid] = s_cnt[tid];
 }
 
 // cvRANSACUpdateNumIters
@@ -474,7 +555,7 @@ void fmat_finalize_k(FmatArgs a)
     uint8_t* status = a.status + (size_t)b * a.capM;
     double* Fout = a.F + (size_t)b * 9;
     __shared__ double s_red[9 * 256];
-    __shared__ double s_A[81], s_V[81], s_d[9], s_F[9];
+    __shared__ double s_A[81], s_V[81], s_d[9], s_F[9], s_bb[9], s_z[9];
     __shared__ int s_n;
     if (best < 0) {
         for (int i = tid; i < M; i += 256) status[i] = 0;
@@ -557,9 +638,8 @@ void fmat_finalize_k(FmatArgs a)
             for (int k = 0; k < 9; k++) s_A[r0 * 9 + k] = acc[k];
         __syncthreads();
     }
+    jacobi_block(s_A, 9, s_d, s_V, s_bb, s_z, tid); // reads the upper triangle only
     if (tid == 0) {
-        for (int i = 0; i < 9; i++) for (int j = 0; j < i; j++) s_A[i * 9 + j] = s_A[j * 9 + i]; // symmetric copy of the upper triangle
-        jacobi_mem(s_A, 9, s_d, s_V);
         const int k0 = argmin_first(s_d, 9);
         double F0[9];
         for (int e = 0; e < 9; e++) F0[e] = s_V[e * 9 + k0];
@@ -1217,7 +1297,7 @@ int mslam_fmat_ransac8_batch_dev(mslam_ctx* ctx, const double* x1, const double*
     hipStream_t st = ctx->stream;
     LAUNCH(ctx, K_FMAT_PREPARE, fmat_prepare_k, dim3(B), dim3(256), 0, a);
     LAUNCH(ctx, K_FMAT_SOLVE, fmat_solve_k, dim3((H + 63) / 64, B), dim3(64), 0, a);
-    LAUNCH(ctx, K_FMAT_SCORE, fmat_score_k, dim3((H + HT - 1) / HT, B), dim3(SCORE_THREADS), 0, a);
+    LAUNCH(ctx, K_FMAT_SCORE, fmat_score_k, dim3((H + FM_HPB - 1) / FM_HPB, B), dim3(SCORE_THREADS), 0, a);
     LAUNCH(ctx, K_RANSAC_SELECT, ransac_select_k, dim3(B), dim3(64), 0, a.counts, M, H, 8, prm->confidence, best_h, (int32_t*)nullptr);
     LAUNCH(ctx, K_FMAT_FINALIZE, fmat_finalize_k, dim3(B), dim3(256), 0, a);
     HIP_TRY(ctx, hipGetLastError());
