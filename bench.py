@@ -61,6 +61,7 @@ def make_pnp(B: int, seed0: int):
 
 def cpu_baseline(frames: np.ndarray, pnp, n_frames: int) -> dict:
     """The oracle (CPU restatement) on this host's cores, single thread like the reference (src/Pipeline.h:57-64)."""
+    frames = frames[: min(len(frames), 8)]
     from oracle import binding as ob
     ob.build()
     X, x, K, dist, samples, _ = pnp
@@ -93,7 +94,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=32, help="independent streams per GPU per step")
+    ap.add_argument("--batch", type=int, default=64, help="independent streams per GPU per step")
+    ap.add_argument("--sub-batches", type=int, default=2, help="the batch is enqueued as this many sub-batches on separate HIP streams")
     ap.add_argument("--cpu-frames", type=int, default=24, help="frames of the cpu_baseline sample (0 = skip)")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip the second, event-instrumented pass")
     ap.add_argument("--overlap", type=int, default=1, help="1: PnP chain on a second context/stream, overlapping extract+match")
@@ -124,19 +126,34 @@ def main():
     from monocular_slam_amd import api
     from monocular_slam_amd.tracking import TrackingBatch
 
-    B = args.batch
-    ctx = api.Context(local_rank, W, H, 4096, B)
-    ctx2 = api.Context(local_rank, W, H, 4096, B) if args.overlap else None
-    tb = TrackingBatch(ctx, B, W, H, NFEAT, cap=NFEAT + 1024, ratio=0.8, pnp_points=PNP_P, pnp_hyps=PNP_H, pnp_ctx=ctx2)
-    frames = make_frames(B, 5005 + 1000 * rank)
-    tb.upload_frames(frames)
-    pnp = make_pnp(B, 3003 + 1000 * rank)
+    B, NS = args.batch, max(1, args.sub_batches)
+    assert B % NS == 0, "--batch must be a multiple of --sub-batches"
+    SB = B // NS
+    # Each sub-batch owns a context (= HIP stream) for extract+match and, with --overlap, a second one for the PnP
+    # chain: kernels of different phases then share the chip (FAST/describe are latency-bound, PnP is f64-VALU-bound).
     pp = api.default_pnp_params()
     pp.reproj_thr = PNP_THR
-    tb.set_pnp_problems(*pnp[:5], pp)
+    tbs, ctxs, frames, pnp = [], [], None, None
+    for i in range(NS):
+        c1 = api.Context(local_rank, W, H, 4096, SB)
+        c2 = api.Context(local_rank, W, H, 4096, SB) if args.overlap else None
+        tb = TrackingBatch(c1, SB, W, H, NFEAT, cap=NFEAT + 1024, ratio=0.8, pnp_points=PNP_P, pnp_hyps=PNP_H, pnp_ctx=c2)
+        f_i = make_frames(SB, 5005 + 1000 * rank + 17 * i)
+        tb.upload_frames(f_i)
+        p_i = make_pnp(SB, 3003 + 1000 * rank + 17 * i)
+        tb.set_pnp_problems(*p_i[:5], pp)
+        if i == 0:
+            frames, pnp = f_i, p_i
+        tbs.append(tb)
+        ctxs += [c for c in (c1, c2) if c is not None]
+
+    def step():
+        for tb in tbs:
+            tb.step()
 
     def barrier():
-        tb.sync()
+        for tb in tbs:
+            tb.sync()
         if dist is not None:
             import torch
             dist.barrier()
@@ -144,11 +161,11 @@ def main():
                 torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        tb.step()
+        step()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        tb.step()
+        step()
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -157,19 +174,22 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    res = tb.results()
-    ok = bool((res["status"] == 0).all() and (res["n"] > NFEAT // 2).all() and (res["ninl"] > PNP_P // 2).all())
+    ok = True
+    for tb in tbs:
+        res = tb.results()
+        ok = ok and bool((res["status"] == 0).all() and (res["n"] > NFEAT // 2).all() and (res["ninl"] > PNP_P // 2).all())
 
     # second pass (rank 0 reports): the same steps with every launch bracketed by HIP events on the
     # context's stream -> per-kernel average duration for the roofline of the dominant kernel
     kern = {}
     if not args.no_kernel_events:
-        for c in {ctx, tb.pnp_ctx}:
+        for c in ctxs:
             c.profile_enable(64 * args.steps)
         for _ in range(args.steps):
-            tb.step()
-        for c in {ctx, tb.pnp_ctx}:
-            kern.update(c.profile_read())
+            step()
+        for c in ctxs:
+            for k, (ms, n) in c.profile_read().items():
+                kern[k] = (kern.get(k, (0.0, 0))[0] + ms, kern.get(k, (0.0, 0))[1] + n)
             c.profile_enable(0)
 
     if rank == 0:
@@ -182,7 +202,9 @@ def main():
             "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]+[2]: 1920x1080 gray frames, ORB nfeatures 2000 (8 levels, 1.2), "
                                    "kNN-2 Hamming + ratio 0.8 vs previous frame, PnP RANSAC 2000 pts x 4096 hyps @ 2 px",
-                       "streams_per_gpu": B, "parallelism": f"{world} x independent streams (no collective)"},
+                       "streams_per_gpu": B, "sub_batches": NS, "frames_per_launch": SB,
+                       "pnp_on_second_stream": bool(args.overlap),
+                       "parallelism": f"{world} GPU(s) x {B} independent streams (no collective)"},
             "valid_outputs": ok,
         }
         if kern:
@@ -191,22 +213,28 @@ def main():
             dom = max(tot, key=tot.get)
             unit = KERNEL_UNIT.get(dom, "extract")
             launches_per_step = kern[dom][1] / args.steps
-            alg = ALG_BYTES[unit] * B / launches_per_step                      # algorithmic bytes per launch
-            achieved = alg / (per[dom] * 1e-3) / 1e9
-            traffic = None
             pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-            if os.path.exists(pmc_path):
-                try:  # PMC passes were collected at the default batch: only comparable per launch at that batch
-                    pmc = json.load(open(pmc_path))
-                    if int(pmc.get("_batch", 32)) == B and world == 1:
-                        traffic = pmc.get(dom, {}).get("hbm_bytes_per_launch")
-                except Exception:
-                    traffic = None
-            out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                               "algorithmic_bytes_per_launch": alg, "avg_launch_ms": per[dom],
-                               "note": "algorithmic bytes (SURVEY 8d) of the %s unit x %d frames / launches per step; "
-                                       "the kernel is VALU/LDS-bound, not HBM-bound (DESIGN.md)" % (unit, B)}
+            def roof(kname):
+                u = KERNEL_UNIT.get(kname, "extract")
+                lps = kern[kname][1] / args.steps
+                alg_k = ALG_BYTES[u] * B / lps
+                ach = alg_k / (per[kname] * 1e-3) / 1e9
+                tr = None
+                if os.path.exists(pmc_path):
+                    try:  # PMC passes were collected at 32 frames per launch: only comparable per launch at that size
+                        pmc = json.load(open(pmc_path))
+                        if int(pmc.get("_batch", 32)) == SB and world == 1:
+                            tr = pmc.get(kname, {}).get("hbm_bytes_per_launch")
+                    except Exception:
+                        tr = None
+                return {"bound": "hbm", "kernel": kname, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                        "traffic": tr, "algorithmic_bytes_per_launch": alg_k, "avg_launch_ms": per[kname], "unit_priced": u}
+
+            out["roofline"] = roof(dom)
+            out["roofline"]["note"] = ("algorithmic bytes (SURVEY 8d) of the %s unit x %d frames per launch; launch duration measured with HIP "
+                                       "events on the launching stream while the other %d streams run; VALU/LDS-bound, not HBM-bound "
+                                       "(DESIGN.md section 4)" % (out["roofline"]["unit_priced"], SB, len(ctxs) - 1))
+            out["roofline_top_kernels"] = [roof(k) for k in sorted(tot, key=tot.get, reverse=True)[:4]]
             out["kernel_ms_per_step"] = {k: v[0] / args.steps for k, v in sorted(kern.items(), key=lambda kv: -kv[1][0])}
         if args.cpu_frames > 0 and world == 1:
             out["cpu_baseline"] = cpu_baseline(frames, pnp, args.cpu_frames)
