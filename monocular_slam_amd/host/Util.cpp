@@ -103,6 +103,28 @@ bool schurSolve(const System& s, double lambda, std::vector<double>& x)
 void Util::BundleAdjustment(DataManager& data, std::vector<Frame>& frames, std::vector<MapPoint>& map_points, int n_iterations,
                             bool /*pb_stop_flag*/, const unsigned long n_loop_kf, const bool b_robust)
 {
+    runBA(data, frames, map_points, n_iterations, b_robust, 1, nullptr, (double)THRESH_HUBER_FULL_BA, n_loop_kf == 0);
+}
+
+void Util::LocalBundleAdjustment(DataManager& data, int first_free_frame_id, int n_iterations, const bool b_robust)
+{
+    runBA(data, data.frames, data.mapPoints, n_iterations, b_robust, first_free_frame_id < 1 ? 1 : first_free_frame_id, nullptr,
+          (double)THRESH_HUBER_FULL_BA, true);
+}
+
+void Util::PoseBundleAdjustment(Frame& frame, DataManager& data, int /*n_round*/)
+{
+    // one round of POSE_BA_ITER iterations (the reference leaves its round loop after the first optimize, :312)
+    runBA(data, data.frames, data.mapPoints, POSE_BA_ITER, true, 0, &frame, (double)THRESH_HUBER, true);
+}
+
+// frames with frameID < first_free_frame_id are fixed (1 == the reference's "fix frame 0", src/Util.cpp:72).
+// only_pose_frame != nullptr: pose-only BA of that frame -- its pose is the single free vertex, every map point it
+// observes is a fixed parameter (EdgeSE3ProjectXYZOnlyPose): no point blocks, a 6x6 system per LM trial.
+void Util::runBA(DataManager& data, std::vector<Frame>& frames, std::vector<MapPoint>& map_points, int n_iterations, bool b_robust,
+                 int first_free_frame_id, Frame* only_pose_frame, double huber_delta, bool write_back)
+{
+    const bool poseOnly = only_pose_frame != nullptr;
     lastChi2History.clear();
     // ---- graph construction (src/Util.cpp:61-169): pose vertices for frames with an Rt, fixed iff frameID == 0
     std::vector<int> poseOfFrame;             // index into `frames`
@@ -112,13 +134,14 @@ void Util::BundleAdjustment(DataManager& data, std::vector<Frame>& frames, std::
     for (size_t i = 0; i < frames.size(); i++) {
         Frame& f = frames[i];
         if (f.Rt.empty()) continue;
+        if (poseOnly && &f != only_pose_frame) continue;
         double Rt[12], p7[7];
         for (int k = 0; k < 12; k++) Rt[k] = f.Rt.at<double>(k / 4, k % 4);
         geom::RtToSE3Quat(Rt, p7);            // Converter::cvMatToSE3Quat
         poseIndexOfId[f.meta.frameID] = (int)poseOfFrame.size();
         poseOfFrame.push_back((int)i);
         poses.insert(poses.end(), p7, p7 + 7);
-        fixed.push_back(f.meta.frameID == 0);
+        fixed.push_back(poseOnly ? 0 : (f.meta.frameID < first_free_frame_id));
         intr.push_back(f.K.at<double>(0, 0)); intr.push_back(f.K.at<double>(1, 1)); intr.push_back(f.K.at<double>(0, 2)); intr.push_back(f.K.at<double>(1, 2));
     }
     // point vertices for map points with at least one observer among those frames; one edge per such observation
@@ -139,6 +162,8 @@ void Util::BundleAdjustment(DataManager& data, std::vector<Frame>& frames, std::
         for (const auto& ob : mp.observers()) {
             Frame* o = findFrameById(data.frames, ob.first);
             if (!o || !poseIndexOfId.count(o->meta.frameID)) continue;
+            if (ob.second < 0 || (size_t)ob.second >= o->features.positions.size() || (size_t)ob.second >= o->features.scales.size())
+                continue; // inconsistent fixture: the reference would read out of bounds here (src/Util.cpp:136,151)
             const cv::Point2f pos(o->features.positions[(size_t)ob.second]);   // truncated to float (:136)
             const float scale = (float)o->features.scales[(size_t)ob.second];  // (:151)
             edge_pose.push_back(poseIndexOfId[o->meta.frameID]); edge_point.push_back(pi);
@@ -151,7 +176,7 @@ void Util::BundleAdjustment(DataManager& data, std::vector<Frame>& frames, std::
     prob.n_poses = (int)poseOfFrame.size(); prob.n_points = (int)mapOfPoint.size(); prob.n_edges = (int)edge_pose.size();
     prob.poses = poses.data(); prob.pose_fixed = fixed.data(); prob.points = points.data();
     prob.edge_pose = edge_pose.data(); prob.edge_point = edge_point.data(); prob.obs = obs.data(); prob.info = info.data();
-    prob.intr = intr.data(); prob.huber_delta = b_robust ? (double)THRESH_HUBER_FULL_BA : 0.0;
+    prob.intr = intr.data(); prob.huber_delta = b_robust ? huber_delta : 0.0;
 
     mslam_ctx* ctx = MslamRuntime::instance().ctx();
     if (!ctx) { MslamRuntime::instance().ensure(640, 480, 1024); ctx = MslamRuntime::instance().ctx(); }
@@ -184,14 +209,24 @@ void Util::BundleAdjustment(DataManager& data, std::vector<Frame>& frames, std::
         if (it == 0) { // computeLambdaInit: tau * max diagonal
             double maxd = 0;
             for (int f = 0; f < s.nf; f++) for (int a = 0; a < 6; a++) maxd = std::max(maxd, std::fabs(s.Hpp[(size_t)36 * f + 7 * a]));
-            for (int i = 0; i < s.npts; i++) for (int a = 0; a < 3; a++) maxd = std::max(maxd, std::fabs(s.Hll[(size_t)9 * i + 4 * a]));
+            if (!poseOnly)
+                for (int i = 0; i < s.npts; i++) for (int a = 0; a < 3; a++) maxd = std::max(maxd, std::fabs(s.Hll[(size_t)9 * i + 4 * a]));
             lambda = 1e-5 * maxd; ni = 2; nBad = 0;
         }
         double rho = 0;
         int qmax = 0;
         do {
             bkPoses = poses; bkPoints = points;                       // push
-            const bool ok2 = schurSolve(s, lambda, x);
+            bool ok2;
+            if (poseOnly) { // BlockSolver without Schur: (Hpp + lambda I) x = b_p
+                std::vector<double> Hd((size_t)36 * s.nf * s.nf, 0.0);
+                const int n6 = 6 * s.nf;
+                for (int f = 0; f < s.nf; f++)
+                    for (int a = 0; a < 6; a++)
+                        for (int c = 0; c < 6; c++) Hd[(size_t)(6 * f + a) * n6 + 6 * f + c] = s.Hpp[(size_t)36 * f + a * 6 + c] + (a == c ? lambda : 0.0);
+                std::fill(x.begin(), x.end(), 0.0);
+                ok2 = geom::ldltSolve(Hd.data(), n6, s.b.data(), x.data());
+            } else ok2 = schurSolve(s, lambda, x);
             for (int j = 0, f = 0; j < prob.n_poses; j++)             // oplus
                 if (!fixed[(size_t)j]) { geom::se3ExpLeft(&x[(size_t)6 * f], &poses[(size_t)7 * j]); f++; }
             for (int i = 0; i < 3 * s.npts; i++) points[(size_t)i] += x[(size_t)6 * s.nf + i];
@@ -201,7 +236,7 @@ void Util::BundleAdjustment(DataManager& data, std::vector<Frame>& frames, std::
             s.robust_chi2 = keepChi;
             rho = currentChi - tempChi;
             double scale = 0;
-            for (int j = 0; j < nx; j++) scale += x[(size_t)j] * (lambda * x[(size_t)j] + s.b[(size_t)j]);
+            for (int j = 0; j < (poseOnly ? 6 * s.nf : nx); j++) scale += x[(size_t)j] * (lambda * x[(size_t)j] + s.b[(size_t)j]);
             scale += 1e-3;
             rho /= scale;
             if (rho > 0 && std::isfinite(tempChi)) {
@@ -223,7 +258,7 @@ void Util::BundleAdjustment(DataManager& data, std::vector<Frame>& frames, std::
     mslam_ba_plan_destroy(plan);
 
     // ---- write back (src/Util.cpp:184-219)
-    if (n_loop_kf == 0) {
+    if (write_back) {
         for (size_t k = 0; k < poseOfFrame.size(); k++) {
             double Rt[12];
             geom::SE3QuatToRt(&poses[7 * k], Rt);                      // Converter::SE3QuatToCvMat
@@ -231,7 +266,7 @@ void Util::BundleAdjustment(DataManager& data, std::vector<Frame>& frames, std::
             for (int q = 0; q < 12; q++) m.at<double>(q / 4, q % 4) = Rt[q];
             frames[(size_t)poseOfFrame[k]].Rt = m;
         }
-        for (size_t k = 0; k < mapOfPoint.size(); k++)
+        for (size_t k = 0; k < mapOfPoint.size() && !poseOnly; k++)
             map_points[(size_t)mapOfPoint[k]].worldPosition = Point3d(points[3 * k], points[3 * k + 1], points[3 * k + 2]);
     }
 }

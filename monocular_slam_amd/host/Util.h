@@ -10,8 +10,26 @@ public:
                                  bool pb_stop_flag = false, const unsigned long n_loop_kf = 0, const bool b_robust = true);
     static void GlobalBundleAdjustemnt(DataManager& data, int n_iterations = 10, bool pb_stop_flag = false,
                                        const unsigned long n_loop_kf = 0, const bool b_robust = true);
+    // Sliding-window variant the reference only declares (src/Util.h:27; LocalMapper is a stub): poses of frames with
+    // frameID < first_free_frame_id are held fixed, later ones and every point they observe are optimised.
+    static void LocalBundleAdjustment(DataManager& data, int first_free_frame_id, int n_iterations = 5, const bool b_robust = true);
+    // Single-pose refinement against fixed map points (src/Util.cpp:222-358: unary EdgeSE3ProjectXYZOnlyPose edges,
+    // Huber delta = sqrt(5.991), POSE_BA_ITER iterations, effectively one round because of the `break` at :312).
+    static void PoseBundleAdjustment(Frame& frame, DataManager& data, int n_round = 5);
     static Frame* findFrameById(std::vector<Frame>& frames, int target_id);
     static MapPoint* findMapPointById(std::vector<MapPoint>& map_points, int target_id);
+    // CSV fixtures in the reference's formats (src/Util.cpp:384-588) and the matching writers (the reference has none)
+    static std::vector<Frame> loadFrames(std::string frame_filename);
+    static std::vector<MapPoint> loadMapPoints(std::string map_points_filename);
+    static std::vector<Frame> loadFramesOnlyIdRt(std::string frame_filename);
+    static std::vector<MapPoint> loadMapPointsOnlyIdXYZ(std::string map_points_filename);
+    static void saveFrames(const std::vector<Frame>& frames, std::string frame_filename);
+    static void saveMapPoints(const std::vector<MapPoint>& map_points, std::string map_points_filename);
+    static void saveFramesOnlyIdRt(const std::vector<Frame>& frames, std::string frame_filename);
+    static void saveMapPointsOnlyIdXYZ(const std::vector<MapPoint>& map_points, std::string map_points_filename);
     // diagnostics of the last BundleAdjustment call: robust chi2 after each outer iteration
     static std::vector<double> lastChi2History;
+private:
+    static void runBA(DataManager& data, std::vector<Frame>& frames, std::vector<MapPoint>& map_points, int n_iterations, bool b_robust,
+                      int first_free_frame_id, Frame* only_pose_frame, double huber_delta, bool write_back);
 };

@@ -376,7 +376,16 @@ static int schur_solve(const orc_ba_system* s, int nf, int npts, double lambda, 
 
 /* SparseOptimizer::optimize(iterations) with OptimizationAlgorithmLevenberg; poses/points updated in place.
  * chi2_history receives the robust chi2 after every outer iteration (optional). Returns iterations run. */
+int orc_ba_optimize_ex(orc_ba_problem* p, double* poses, double* points, int iterations, int points_fixed, double* chi2_history, int* n_hist);
+
 int orc_ba_optimize(orc_ba_problem* p, double* poses, double* points, int iterations, double* chi2_history, int* n_hist)
+{
+    return orc_ba_optimize_ex(p, poses, points, iterations, 0, chi2_history, n_hist);
+}
+
+/* points_fixed != 0: pose-only BA (Util::PoseBundleAdjustment, src/Util.cpp:222-358: EdgeSE3ProjectXYZOnlyPose unary edges,
+ * BlockSolver without marginalised vertices): only the pose blocks enter the system, the points never move. */
+int orc_ba_optimize_ex(orc_ba_problem* p, double* poses, double* points, int iterations, int points_fixed, double* chi2_history, int* n_hist)
 {
     int nf = 0, nnzb = 0;
     p->poses = poses; p->points = points;
@@ -406,7 +415,8 @@ int orc_ba_optimize(orc_ba_problem* p, double* poses, double* points, int iterat
         if (it == 0) { /* computeLambdaInit: tau * max |H_jj| */
             double maxd = 0;
             for (int f = 0; f < nf; f++) for (int a = 0; a < 6; a++) { double v = fabs(s.Hpp[36 * f + 7 * a]); if (v > maxd) maxd = v; }
-            for (int i = 0; i < p->n_points; i++) for (int a = 0; a < 3; a++) { double v = fabs(s.Hll[9 * i + 4 * a]); if (v > maxd) maxd = v; }
+            if (!points_fixed)
+                for (int i = 0; i < p->n_points; i++) for (int a = 0; a < 3; a++) { double v = fabs(s.Hll[9 * i + 4 * a]); if (v > maxd) maxd = v; }
             lambda = 1e-5 * maxd; ni = 2; nbad = 0;
         }
         double rho = 0;
@@ -414,7 +424,16 @@ int orc_ba_optimize(orc_ba_problem* p, double* poses, double* points, int iterat
         do {
             memcpy(bk_pose, poses, sizeof(double) * 7 * (size_t)p->n_poses);   /* push */
             memcpy(bk_pts, points, sizeof(double) * 3 * (size_t)p->n_points);
-            int ok2 = schur_solve(&s, nf, p->n_points, lambda, x);
+            int ok2;
+            if (points_fixed) {
+                double* Hd = (double*)calloc((size_t)np6 * np6 + 1, sizeof(double));
+                for (int f = 0; f < nf; f++)
+                    for (int a = 0; a < 6; a++)
+                        for (int c = 0; c < 6; c++) Hd[(6 * f + a) * np6 + 6 * f + c] = s.Hpp[36 * f + a * 6 + c] + (a == c ? lambda : 0.0);
+                memset(x, 0, sizeof(double) * (size_t)nx);
+                ok2 = ldlt_solve(Hd, np6, s.b, x);
+                free(Hd);
+            } else ok2 = schur_solve(&s, nf, p->n_points, lambda, x);
             /* update (oplus) */
             for (int j = 0; j < p->n_poses; j++) if (fidx[j] >= 0) orc_se3_exp_left(x + 6 * fidx[j], poses + 7 * j);
             for (int i = 0; i < 3 * p->n_points; i++) points[i] += x[np6 + i];
@@ -422,7 +441,7 @@ int orc_ba_optimize(orc_ba_problem* p, double* poses, double* points, int iterat
             if (!ok2) tempChi = DBL_MAX;
             rho = currentChi - tempChi;
             double scale = 0;
-            for (int j = 0; j < nx; j++) scale += x[j] * (lambda * x[j] + s.b[j]);
+            for (int j = 0; j < (points_fixed ? np6 : nx); j++) scale += x[j] * (lambda * x[j] + s.b[j]);
             scale += 1e-3;
             rho /= scale;
             if (rho > 0 && isfinite(tempChi)) {

@@ -241,10 +241,10 @@ def ba_build(pr):
     return a
 
 
-def ba_optimize(pr, iterations: int):
+def ba_optimize(pr, iterations: int, points_fixed: bool = False):
     ps, keep = _ba_problem_struct(pr)
     poses = keep["poses"].copy(); points = keep["points"].copy()
     hist = np.zeros(iterations + 1); nh = C.c_int(0)
-    lib().orc_ba_optimize.restype = C.c_int
-    done = lib().orc_ba_optimize(C.byref(ps), _p(poses, f64p), _p(points, f64p), iterations, _p(hist, f64p), C.byref(nh))
+    lib().orc_ba_optimize_ex.restype = C.c_int
+    done = lib().orc_ba_optimize_ex(C.byref(ps), _p(poses, f64p), _p(points, f64p), iterations, int(points_fixed), _p(hist, f64p), C.byref(nh))
     return dict(poses=poses, points=points, chi2=hist[: nh.value].copy(), iterations=done)
