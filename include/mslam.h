@@ -302,6 +302,21 @@ int mslam_ba_plan_build_dev(mslam_ba_plan* plan);
 /* copy the built system to host buffers (syncs) */
 int mslam_ba_plan_download(mslam_ba_plan* plan, mslam_ba_system* s);
 
+/* Schur complement of the built system on the device (g2o: BlockSolver::solve,
+ * block_solver.hpp:372-481): with lambda added to every pose and landmark diagonal (setLambda, :564-589),
+ *   S   = Hpp - sum_i Hpl_i Hll_i^-1 Hpl_i^T      (6 fp x 6 fp, dense, row-major, both triangles)
+ *   b_s = b_p - sum_i Hpl_i Hll_i^-1 b_l,i
+ * The caller solves S x_p = b_s (small, host), then mslam_ba_plan_backsub_dev computes x_l = Hll^-1 (b_l - Hpl^T x_p)
+ * on the device, optionally applies X += x_l to the plan's points, and reduces sum x_l (lambda x_l + b_l)
+ * (the landmark part of LM's computeScale).  mslam_ba_plan_points_snapshot_dev(restore=0/1) saves / restores the
+ * points for rejected LM steps.  MSLAM_ERR_CAPACITY if the plan was built without Schur scratch. */
+int mslam_ba_plan_schur_dev(mslam_ba_plan* plan, double lambda);
+int mslam_ba_plan_download_schur(mslam_ba_plan* plan, double* S, double* b_s);
+int mslam_ba_plan_backsub_dev(mslam_ba_plan* plan, const double* x_pose_host, int apply_to_points);
+int mslam_ba_plan_download_x(mslam_ba_plan* plan, double* x /* 6 fp + 3 n_points, optional */, double* scale_landmarks /* optional */);
+int mslam_ba_plan_points_snapshot_dev(mslam_ba_plan* plan, int restore);
+int mslam_ba_plan_get_state(mslam_ba_plan* plan, double* poses_host, double* points_host);
+
 /* ---- multi-GPU -------------------------------------------------------------------------
  * The path shards by independent streams (one process per GPU, no data-path collective).
  * The only exchange is the optional sharding of ONE problem's hypotheses over ranks:

@@ -125,8 +125,19 @@ class Context:
 
     def close(self):
         if getattr(self, "_h", None):
+            for child in list(getattr(self, "_children", [])):   # plans / buffers must go before their context
+                try:
+                    child.close() if hasattr(child, "close") else child.free()
+                except Exception:
+                    pass
             lib().mslam_destroy(self._h)
             self._h = None
+
+    def _adopt(self, child):
+        import weakref
+        if not hasattr(self, "_children"):
+            self._children = weakref.WeakSet()
+        self._children.add(child)
 
     def __del__(self):
         try:
@@ -267,6 +278,7 @@ class BaPlan:
         ctx._check(lib().mslam_ba_plan_create(ctx.handle, C.byref(ps), C.byref(self._h)), "mslam_ba_plan_create")
         self.view = BaDevView()
         ctx._check(lib().mslam_ba_plan_view(self._h, C.byref(self.view)), "mslam_ba_plan_view")
+        ctx._adopt(self)
 
     def set_state(self, poses=None, points=None):
         a = np.ascontiguousarray(poses, np.float64) if poses is not None else None
@@ -284,6 +296,33 @@ class BaPlan:
         a["Hpl_col"] = a["Hpl_col"][:nnzb]; a["Hpl_val"] = a["Hpl_val"][:nnzb]
         a.update(robust_chi2=ss.robust_chi2, n_free_poses=ss.n_free_poses, nnzb=ss.nnzb)
         return a
+
+    # ---- Schur complement on the device (f1)
+    def schur_dev(self, lam: float):
+        self.ctx._check(lib().mslam_ba_plan_schur_dev(self._h, C.c_double(lam)), "mslam_ba_plan_schur_dev")
+
+    def download_schur(self):
+        n6 = 6 * self.view.n_free_poses
+        S = np.zeros((n6, n6)); bs = np.zeros(n6)
+        self.ctx._check(lib().mslam_ba_plan_download_schur(self._h, _p(S, f64p), _p(bs, f64p)), "mslam_ba_plan_download_schur")
+        return S, bs
+
+    def backsub_dev(self, x_pose: np.ndarray, apply_to_points: bool = False):
+        xp = np.ascontiguousarray(x_pose, np.float64)
+        self.ctx._check(lib().mslam_ba_plan_backsub_dev(self._h, _p(xp, f64p), int(apply_to_points)), "mslam_ba_plan_backsub_dev")
+
+    def download_x(self):
+        x = np.zeros(6 * self.view.n_free_poses + 3 * self.pr["n_points"]); sc = C.c_double(0)
+        self.ctx._check(lib().mslam_ba_plan_download_x(self._h, _p(x, f64p), C.byref(sc)), "mslam_ba_plan_download_x")
+        return x, sc.value
+
+    def points_snapshot_dev(self, restore: bool):
+        self.ctx._check(lib().mslam_ba_plan_points_snapshot_dev(self._h, int(restore)), "mslam_ba_plan_points_snapshot_dev")
+
+    def get_state(self):
+        poses = np.zeros((self.pr["n_poses"], 7)); points = np.zeros((self.pr["n_points"], 3))
+        self.ctx._check(lib().mslam_ba_plan_get_state(self._h, _p(poses, f64p), _p(points, f64p)), "mslam_ba_plan_get_state")
+        return poses, points
 
     def close(self):
         if getattr(self, "_h", None) and self._h.value:
@@ -386,6 +425,7 @@ class DevBuf:
         self.nbytes = int(nbytes)
         self._p = vp()
         ctx._check(lib().mslam_dev_alloc(ctx.handle, C.byref(self._p), C.c_uint64(max(1, self.nbytes))), "mslam_dev_alloc")
+        ctx._adopt(self)
 
     @classmethod
     def from_array(cls, ctx: Context, a: np.ndarray) -> "DevBuf":

@@ -51,6 +51,22 @@ struct BaDev {
     double* pt_rho;           // [n_points] robust chi2 per point
     double* pose_part;        // [n_free][n_chunks_max][27]
     double* robust_chi2;      // [1]
+    // ---- Schur complement (f1): reduced pose system S x_p = b_s, landmark back-substitution
+    const int32_t* col;       // [nnzb] point of a block
+    const int32_t* blk_of;    // [n_free][n_points] block of (pose row, point) or -1
+    double* Dinv;             // [n_points][9]  (Hll + lambda I)^-1
+    double* db;               // [n_points][3]  Dinv b_l
+    double* BD;               // [nnzb][18]     B Dinv
+    double* cblk;             // [nnzb][6]      B (Dinv b_l)
+    double* pair_part;        // [npairs][n_chunks_max][36]
+    double* coef_part;        // [n_free][n_chunks_max][6]
+    double* S;                // [6 n_free][6 n_free]
+    double* bs;               // [6 n_free]
+    double* x;                // [6 n_free + 3 n_points]
+    double* points_bk;        // [n_points][3] snapshot for rejected LM steps
+    double* scale_part;       // [ceil(n_points/256)] partial sums of x_l (lambda x_l + b_l)
+    double* scale_l;          // [1]
+    double lambda;
 };
 
 struct EdgeLin { double e0, e1, A[6], B[12]; };
@@ -227,6 +243,163 @@ void ba_final_k(BaDev d)
     if (tid == 0) d.robust_chi2[0] = s_r[0];
 }
 
+// ---- Schur complement on the device (BlockSolver::solve, block_solver.hpp:372-481)
+__global__ __launch_bounds__(256)
+void ba_schur_points_k(BaDev d)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= d.n_points) return;
+    double M[9];
+#pragma unroll
+    for (int q = 0; q < 9; q++) M[q] = d.Hll[(size_t)i * 9 + q];
+    M[0] += d.lambda; M[4] += d.lambda; M[8] += d.lambda;
+    const double det = M[0] * (M[4] * M[8] - M[5] * M[7]) - M[1] * (M[3] * M[8] - M[5] * M[6]) + M[2] * (M[3] * M[7] - M[4] * M[6]);
+    const double id = 1.0 / det;
+    double I[9];
+    I[0] = (M[4] * M[8] - M[5] * M[7]) * id; I[1] = (M[2] * M[7] - M[1] * M[8]) * id; I[2] = (M[1] * M[5] - M[2] * M[4]) * id;
+    I[3] = (M[5] * M[6] - M[3] * M[8]) * id; I[4] = (M[0] * M[8] - M[2] * M[6]) * id; I[5] = (M[2] * M[3] - M[0] * M[5]) * id;
+    I[6] = (M[3] * M[7] - M[4] * M[6]) * id; I[7] = (M[1] * M[6] - M[0] * M[7]) * id; I[8] = (M[0] * M[4] - M[1] * M[3]) * id;
+    const double* bl = d.b + 6 * d.n_free + 3 * (size_t)i;
+#pragma unroll
+    for (int q = 0; q < 9; q++) d.Dinv[(size_t)i * 9 + q] = I[q];
+#pragma unroll
+    for (int a = 0; a < 3; a++) d.db[(size_t)i * 3 + a] = I[a * 3] * bl[0] + I[a * 3 + 1] * bl[1] + I[a * 3 + 2] * bl[2];
+}
+
+__global__ __launch_bounds__(256)
+void ba_schur_blocks_k(BaDev d)
+{
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= d.nnzb) return;
+    const int i = d.col[k];
+    const double* B = d.Hpl_val + (size_t)k * 18;
+    const double* Di = d.Dinv + (size_t)i * 9;
+    const double* dbi = d.db + (size_t)i * 3;
+#pragma unroll
+    for (int a = 0; a < 6; a++) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) d.BD[(size_t)k * 18 + a * 3 + c] = B[a * 3] * Di[c] + B[a * 3 + 1] * Di[3 + c] + B[a * 3 + 2] * Di[6 + c];
+        d.cblk[(size_t)k * 6 + a] = B[a * 3] * dbi[0] + B[a * 3 + 1] * dbi[1] + B[a * 3 + 2] * dbi[2];
+    }
+}
+
+// grid (chunk, pair): pair p <-> (j1 <= j2); lanes walk the blocks of pose row j1, look up the block of (j2, same point)
+__global__ __launch_bounds__(POSE_CHUNK)
+void ba_schur_pairs_k(BaDev d)
+{
+    const int chunk = blockIdx.x, tid = threadIdx.x;
+    int j1 = 0, rem = blockIdx.y; // unpack the upper-triangle pair index
+    while (rem >= d.n_free - j1) { rem -= d.n_free - j1; j1++; }
+    const int j2 = j1 + rem;
+    const int k0 = d.rowptr[j1], k1 = d.rowptr[j1 + 1];
+    if (k0 + chunk * POSE_CHUNK >= k1) return;
+    const int k = k0 + chunk * POSE_CHUNK + tid;
+    __shared__ double s_red[42 * POSE_CHUNK];
+    double v[42];
+#pragma unroll
+    for (int q = 0; q < 42; q++) v[q] = 0.0;
+    if (k < k1) {
+        const int i = d.col[k];
+        const int k2 = d.blk_of[(size_t)j2 * d.n_points + i];
+        if (k2 >= 0) {
+            const double* BDk = d.BD + (size_t)k * 18;
+            const double* Bj = d.Hpl_val + (size_t)k2 * 18;
+#pragma unroll
+            for (int a = 0; a < 6; a++)
+#pragma unroll
+                for (int c = 0; c < 6; c++) v[a * 6 + c] = BDk[a * 3] * Bj[c * 3] + BDk[a * 3 + 1] * Bj[c * 3 + 1] + BDk[a * 3 + 2] * Bj[c * 3 + 2];
+        }
+        if (j1 == j2)
+#pragma unroll
+            for (int a = 0; a < 6; a++) v[36 + a] = d.cblk[(size_t)k * 6 + a];
+    }
+#pragma unroll
+    for (int q = 0; q < 42; q++) s_red[q * POSE_CHUNK + tid] = v[q];
+    __syncthreads();
+    for (int o = POSE_CHUNK / 2; o > 0; o >>= 1) {
+        if (tid < o)
+#pragma unroll
+            for (int q = 0; q < 42; q++) s_red[q * POSE_CHUNK + tid] += s_red[q * POSE_CHUNK + tid + o];
+        __syncthreads();
+    }
+    if (tid < 36) d.pair_part[((size_t)blockIdx.y * d.n_chunks_max + chunk) * 36 + tid] = s_red[tid * POSE_CHUNK];
+    else if (tid < 42 && j1 == j2) d.coef_part[((size_t)j1 * d.n_chunks_max + chunk) * 6 + (tid - 36)] = s_red[tid * POSE_CHUNK];
+}
+
+__global__ __launch_bounds__(256)
+void ba_schur_final_k(BaDev d)
+{
+    const int np6 = 6 * d.n_free;
+    const int npairs = d.n_free * (d.n_free + 1) / 2;
+    for (int t = blockIdx.x * 256 + threadIdx.x; t < npairs * 36; t += gridDim.x * 256) {
+        const int p = t / 36, e = t % 36, a = e / 6, c = e % 6;
+        int j1 = 0, rem = p;
+        while (rem >= d.n_free - j1) { rem -= d.n_free - j1; j1++; }
+        const int j2 = j1 + rem;
+        const int nch = (d.rowptr[j1 + 1] - d.rowptr[j1] + POSE_CHUNK - 1) / POSE_CHUNK;
+        double sum = 0.0;
+        for (int ch = 0; ch < nch; ch++) sum += d.pair_part[((size_t)p * d.n_chunks_max + ch) * 36 + e];
+        double val = -sum;
+        if (j1 == j2) val += d.Hpp[(size_t)j1 * 36 + e] + (a == c ? d.lambda : 0.0);
+        d.S[(size_t)(6 * j1 + a) * np6 + 6 * j2 + c] = val;
+        if (j1 != j2) d.S[(size_t)(6 * j2 + c) * np6 + 6 * j1 + a] = val;
+    }
+    for (int t = blockIdx.x * 256 + threadIdx.x; t < np6; t += gridDim.x * 256) {
+        const int j = t / 6, a = t % 6;
+        const int nch = (d.rowptr[j + 1] - d.rowptr[j] + POSE_CHUNK - 1) / POSE_CHUNK;
+        double sum = 0.0;
+        for (int ch = 0; ch < nch; ch++) sum += d.coef_part[((size_t)j * d.n_chunks_max + ch) * 6 + a];
+        d.bs[t] = d.b[t] - sum;
+    }
+}
+
+// x_l = Dinv (b_l - Hpl^T x_p); optional X += x_l; per-block partial of x_l . (lambda x_l + b_l) for computeScale
+__global__ __launch_bounds__(256)
+void ba_backsub_k(BaDev d, int apply, double* points_rw)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x, tid = threadIdx.x;
+    double sc = 0.0;
+    if (i < d.n_points) {
+        const double* bl = d.b + 6 * d.n_free + 3 * (size_t)i;
+        double cl[3] = { bl[0], bl[1], bl[2] };
+        for (int q = d.pt_ptr[i]; q < d.pt_ptr[i + 1]; q++) {
+            const int e = d.pt_edge[q];
+            const int sl = d.slot[e];
+            if (sl < 0) continue;
+            const double* B = d.Hpl_val + (size_t)sl * 18;
+            const double* xp = d.x + 6 * d.fidx[d.edge_pose[e]];
+#pragma unroll
+            for (int c = 0; c < 3; c++)
+#pragma unroll
+                for (int a = 0; a < 6; a++) cl[c] -= B[a * 3 + c] * xp[a];
+        }
+        const double* Di = d.Dinv + (size_t)i * 9;
+        double xl[3];
+#pragma unroll
+        for (int a = 0; a < 3; a++) xl[a] = Di[a * 3] * cl[0] + Di[a * 3 + 1] * cl[1] + Di[a * 3 + 2] * cl[2];
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            d.x[6 * d.n_free + 3 * (size_t)i + a] = xl[a];
+            sc += xl[a] * (d.lambda * xl[a] + bl[a]);
+            if (apply) points_rw[3 * (size_t)i + a] += xl[a];
+        }
+    }
+    __shared__ double s_r[256];
+    s_r[tid] = sc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (tid < o) s_r[tid] += s_r[tid + o]; __syncthreads(); }
+    if (tid == 0) d.scale_part[blockIdx.x] = s_r[0];
+}
+
+__global__ void ba_scale_final_k(BaDev d, int nblocks)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        double s = 0.0;
+        for (int q = 0; q < nblocks; q++) s += d.scale_part[q];
+        d.scale_l[0] = s;
+    }
+}
+
 } // namespace
 
 struct mslam_ba_plan {
@@ -236,6 +409,7 @@ struct mslam_ba_plan {
     double* d_poses = nullptr; double* d_points = nullptr;
     int32_t* d_rowptr = nullptr; int32_t* d_col = nullptr;
     std::vector<int32_t> h_rowptr, h_col;
+    bool has_schur = false;
 };
 
 static int ba_validate(const mslam_ba_problem* p)
@@ -311,6 +485,18 @@ int mslam_ba_plan_create(mslam_ctx* ctx, const mslam_ba_problem* p, mslam_ba_pla
                  o_hpl = reserve(sizeof(double) * 18 * std::max(nnzb, 1)), o_b = reserve(sizeof(double) * (6 * nf + 3 * NL)),
                  o_ptr = reserve(sizeof(double) * NL), o_pp = reserve(sizeof(double) * 27 * (size_t)std::max(nf, 1) * n_chunks_max),
                  o_rc = reserve(sizeof(double));
+    // Schur scratch (dense pose-row x point lookup: fine for local-BA sizes; skipped when it would be huge)
+    const bool want_schur = (size_t)nf * NL <= ((size_t)1 << 26) && nf > 0 && nnzb > 0;
+    const int npairs = nf * (nf + 1) / 2;
+    size_t o_blk = 0, o_dinv = 0, o_db = 0, o_bd = 0, o_cb = 0, o_pp2 = 0, o_cp = 0, o_S = 0, o_bs = 0, o_x = 0, o_bk = 0, o_sp = 0, o_sl = 0;
+    if (want_schur) {
+        o_blk = reserve(sizeof(int32_t) * (size_t)nf * NL); o_dinv = reserve(sizeof(double) * 9 * NL); o_db = reserve(sizeof(double) * 3 * NL);
+        o_bd = reserve(sizeof(double) * 18 * nnzb); o_cb = reserve(sizeof(double) * 6 * nnzb);
+        o_pp2 = reserve(sizeof(double) * 36 * (size_t)npairs * n_chunks_max); o_cp = reserve(sizeof(double) * 6 * (size_t)nf * n_chunks_max);
+        o_S = reserve(sizeof(double) * 36 * (size_t)nf * nf); o_bs = reserve(sizeof(double) * 6 * nf);
+        o_x = reserve(sizeof(double) * (6 * nf + 3 * NL)); o_bk = reserve(sizeof(double) * 3 * NL);
+        o_sp = reserve(sizeof(double) * ((NL + 255) / 256)); o_sl = reserve(sizeof(double));
+    }
     hipError_t he = hipMalloc(&pl->arena, bytes);
     if (he != hipSuccess) { ctx->last_hip_error = std::string("hipMalloc(ba plan): ") + hipGetErrorString(he); delete pl; return MSLAM_ERR_HIP; }
     char* base = (char*)pl->arena;
@@ -340,6 +526,19 @@ int mslam_ba_plan_create(mslam_ctx* ctx, const mslam_ba_problem* p, mslam_ba_pla
     pl->d_poses = (double*)(base + o_poses); pl->d_points = (double*)(base + o_points);
     pl->d_rowptr = (int32_t*)(base + o_row); pl->d_col = (int32_t*)(base + o_col);
     pl->h_rowptr = rowptr; pl->h_col = col;
+    d.col = (int32_t*)(base + o_col);
+    if (want_schur) {
+        std::vector<int32_t> blk_of((size_t)nf * NL, -1);
+        for (int f = 0; f < nf; f++)
+            for (int k = rowptr[f]; k < rowptr[f + 1]; k++) blk_of[(size_t)f * NL + col[k]] = k;
+        hipError_t e2 = hipMemcpy(base + o_blk, blk_of.data(), sizeof(int32_t) * blk_of.size(), hipMemcpyHostToDevice);
+        if (e2 != hipSuccess) { ctx->last_hip_error = std::string("ba plan upload: ") + hipGetErrorString(e2); (void)hipFree(pl->arena); delete pl; return MSLAM_ERR_HIP; }
+        d.blk_of = (int32_t*)(base + o_blk); d.Dinv = (double*)(base + o_dinv); d.db = (double*)(base + o_db); d.BD = (double*)(base + o_bd);
+        d.cblk = (double*)(base + o_cb); d.pair_part = (double*)(base + o_pp2); d.coef_part = (double*)(base + o_cp);
+        d.S = (double*)(base + o_S); d.bs = (double*)(base + o_bs); d.x = (double*)(base + o_x); d.points_bk = (double*)(base + o_bk);
+        d.scale_part = (double*)(base + o_sp); d.scale_l = (double*)(base + o_sl);
+        pl->has_schur = true;
+    }
     *out = pl;
     return MSLAM_OK;
 }
@@ -408,6 +607,81 @@ int mslam_ba_plan_download(mslam_ba_plan* pl, mslam_ba_system* s)
     if (s->Hpl_rowptr) std::memcpy(s->Hpl_rowptr, pl->h_rowptr.data(), sizeof(int32_t) * (d.n_free + 1));
     if (s->Hpl_col && d.nnzb) std::memcpy(s->Hpl_col, pl->h_col.data(), sizeof(int32_t) * d.nnzb);
     s->n_free_poses = d.n_free; s->nnzb = d.nnzb;
+    return MSLAM_OK;
+}
+
+int mslam_ba_plan_schur_dev(mslam_ba_plan* pl, double lambda)
+{
+    if (!pl) return MSLAM_ERR_INVALID;
+    if (!pl->has_schur) return MSLAM_ERR_CAPACITY;
+    mslam_ctx* ctx = pl->ctx;
+    BaDev d = pl->dev;
+    d.lambda = lambda;
+    pl->dev.lambda = lambda;
+    const int npairs = d.n_free * (d.n_free + 1) / 2;
+    LAUNCH(ctx, K_BA_SCHUR, ba_schur_points_k, dim3((d.n_points + 255) / 256), dim3(256), 0, d);
+    LAUNCH(ctx, K_BA_SCHUR, ba_schur_blocks_k, dim3((d.nnzb + 255) / 256), dim3(256), 0, d);
+    LAUNCH(ctx, K_BA_SCHUR, ba_schur_pairs_k, dim3(d.n_chunks_max, npairs), dim3(POSE_CHUNK), 0, d);
+    LAUNCH(ctx, K_BA_SCHUR, ba_schur_final_k, dim3(std::min(64, (npairs * 36 + 255) / 256)), dim3(256), 0, d);
+    HIP_TRY(ctx, hipGetLastError());
+    return MSLAM_OK;
+}
+
+int mslam_ba_plan_download_schur(mslam_ba_plan* pl, double* S, double* bs)
+{
+    if (!pl || !pl->has_schur) return MSLAM_ERR_INVALID;
+    mslam_ctx* ctx = pl->ctx;
+    const BaDev& d = pl->dev;
+    const size_t n6 = 6 * (size_t)d.n_free;
+    if (S) HIP_TRY(ctx, hipMemcpyAsync(S, d.S, sizeof(double) * n6 * n6, hipMemcpyDeviceToHost, ctx->stream));
+    if (bs) HIP_TRY(ctx, hipMemcpyAsync(bs, d.bs, sizeof(double) * n6, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return MSLAM_OK;
+}
+
+int mslam_ba_plan_backsub_dev(mslam_ba_plan* pl, const double* x_pose_host, int apply_to_points)
+{
+    if (!pl || !pl->has_schur || !x_pose_host) return MSLAM_ERR_INVALID;
+    mslam_ctx* ctx = pl->ctx;
+    const BaDev& d = pl->dev;
+    HIP_TRY(ctx, hipMemcpyAsync(d.x, x_pose_host, sizeof(double) * 6 * d.n_free, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); // x_pose_host may be a temporary of the caller
+    const int nb = (d.n_points + 255) / 256;
+    LAUNCH(ctx, K_BA_SCHUR, ba_backsub_k, dim3(nb), dim3(256), 0, d, apply_to_points, pl->d_points);
+    LAUNCH(ctx, K_BA_SCHUR, ba_scale_final_k, dim3(1), dim3(64), 0, d, nb);
+    HIP_TRY(ctx, hipGetLastError());
+    return MSLAM_OK;
+}
+
+int mslam_ba_plan_download_x(mslam_ba_plan* pl, double* x, double* scale_landmarks)
+{
+    if (!pl || !pl->has_schur) return MSLAM_ERR_INVALID;
+    mslam_ctx* ctx = pl->ctx;
+    const BaDev& d = pl->dev;
+    if (x) HIP_TRY(ctx, hipMemcpyAsync(x, d.x, sizeof(double) * (6 * d.n_free + 3 * (size_t)d.n_points), hipMemcpyDeviceToHost, ctx->stream));
+    if (scale_landmarks) HIP_TRY(ctx, hipMemcpyAsync(scale_landmarks, d.scale_l, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return MSLAM_OK;
+}
+
+int mslam_ba_plan_points_snapshot_dev(mslam_ba_plan* pl, int restore)
+{
+    if (!pl || !pl->has_schur) return MSLAM_ERR_INVALID;
+    mslam_ctx* ctx = pl->ctx;
+    const BaDev& d = pl->dev;
+    const size_t n = sizeof(double) * 3 * (size_t)d.n_points;
+    if (restore) HIP_TRY(ctx, hipMemcpyAsync(pl->d_points, d.points_bk, n, hipMemcpyDeviceToDevice, ctx->stream));
+    else HIP_TRY(ctx, hipMemcpyAsync(d.points_bk, pl->d_points, n, hipMemcpyDeviceToDevice, ctx->stream));
+    return MSLAM_OK;
+}
+
+int mslam_ba_plan_get_state(mslam_ba_plan* pl, double* poses, double* points)
+{
+    if (!pl) return MSLAM_ERR_INVALID;
+    mslam_ctx* ctx = pl->ctx;
+    if (poses) HIP_TRY(ctx, hipMemcpyAsync(poses, pl->d_poses, sizeof(double) * 7 * pl->dev.n_poses, hipMemcpyDeviceToHost, ctx->stream));
+    if (points) HIP_TRY(ctx, hipMemcpyAsync(points, pl->d_points, sizeof(double) * 3 * pl->dev.n_points, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return MSLAM_OK;
 }
 

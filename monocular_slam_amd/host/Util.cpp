@@ -197,11 +197,21 @@ void Util::runBA(DataManager& data, std::vector<Frame>& frames, std::vector<MapP
         s.robust_chi2 = v.robust_chi2;
     };
 
-    // ---- OptimizationAlgorithmLevenberg::solve per outer iteration (optimization_algorithm_levenberg.cpp:61-164)
-    const int nx = 6 * s.nf + 3 * s.npts;
-    std::vector<double> x((size_t)nx, 0.0), bkPoses, bkPoints;
+    // ---- OptimizationAlgorithmLevenberg::solve per outer iteration (optimization_algorithm_levenberg.cpp:61-164).
+    // Full BA: the Schur complement and the landmark back-substitution run on the device (mslam_ba_plan_schur_dev /
+    // _backsub_dev); per LM trial the host only sees the reduced pose system (6 fp x 6 fp), solves it by LDL^T, updates
+    // the poses (SE3 exp) and reads back one chi2.  Pose-only BA and plans without Schur scratch use the host solve.
+    const int nx = 6 * s.nf + 3 * s.npts, n6 = 6 * s.nf;
+    std::vector<double> x((size_t)nx, 0.0), bkPoses, bkPoints, S((size_t)n6 * n6), bsv((size_t)n6);
+    bool gpuSchur = !poseOnly && mslam_ba_plan_schur_dev(plan, 0.0) == MSLAM_OK; // probe (MSLAM_ERR_CAPACITY: not available)
     double lambda = -1, ni = 2;
     int nBad = 0;
+    auto chi2_only = [&]() {
+        MslamRuntime::check(mslam_ba_plan_build_dev(plan), "mslam_ba_plan_build_dev");
+        mslam_ba_system v{};
+        MslamRuntime::check(mslam_ba_plan_download(plan, &v), "mslam_ba_plan_download");
+        return v.robust_chi2;
+    };
     for (int it = 0; it < n_iterations; it++) {
         linearise(true);
         double currentChi = s.robust_chi2, tempChi = currentChi;
@@ -216,27 +226,42 @@ void Util::runBA(DataManager& data, std::vector<Frame>& frames, std::vector<MapP
         double rho = 0;
         int qmax = 0;
         do {
-            bkPoses = poses; bkPoints = points;                       // push
+            bkPoses = poses;                                            // push
+            if (gpuSchur) MslamRuntime::check(mslam_ba_plan_points_snapshot_dev(plan, 0), "points_snapshot");
+            else bkPoints = points;
             bool ok2;
+            double scale = 0;
             if (poseOnly) { // BlockSolver without Schur: (Hpp + lambda I) x = b_p
-                std::vector<double> Hd((size_t)36 * s.nf * s.nf, 0.0);
-                const int n6 = 6 * s.nf;
+                std::vector<double> Hd((size_t)n6 * n6, 0.0);
                 for (int f = 0; f < s.nf; f++)
                     for (int a = 0; a < 6; a++)
                         for (int c = 0; c < 6; c++) Hd[(size_t)(6 * f + a) * n6 + 6 * f + c] = s.Hpp[(size_t)36 * f + a * 6 + c] + (a == c ? lambda : 0.0);
                 std::fill(x.begin(), x.end(), 0.0);
                 ok2 = geom::ldltSolve(Hd.data(), n6, s.b.data(), x.data());
+            } else if (gpuSchur) {
+                MslamRuntime::check(mslam_ba_plan_schur_dev(plan, lambda), "mslam_ba_plan_schur_dev");
+                MslamRuntime::check(mslam_ba_plan_download_schur(plan, S.data(), bsv.data()), "mslam_ba_plan_download_schur");
+                ok2 = n6 == 0 || geom::ldltSolve(S.data(), n6, bsv.data(), x.data());
+                if (!ok2) std::fill(x.begin(), x.begin() + n6, 0.0);
+                MslamRuntime::check(mslam_ba_plan_backsub_dev(plan, x.data(), 1), "mslam_ba_plan_backsub_dev"); // X += x_l on the device
+                MslamRuntime::check(mslam_ba_plan_download_x(plan, nullptr, &scale), "mslam_ba_plan_download_x");
             } else ok2 = schurSolve(s, lambda, x);
-            for (int j = 0, f = 0; j < prob.n_poses; j++)             // oplus
+            for (int j = 0, f = 0; j < prob.n_poses; j++)             // oplus on the poses
                 if (!fixed[(size_t)j]) { geom::se3ExpLeft(&x[(size_t)6 * f], &poses[(size_t)7 * j]); f++; }
-            for (int i = 0; i < 3 * s.npts; i++) points[(size_t)i] += x[(size_t)6 * s.nf + i];
-            const double keepChi = s.robust_chi2;
-            linearise(false);                                          // computeActiveErrors + activeRobustChi2
-            tempChi = ok2 ? s.robust_chi2 : DBL_MAX;
-            s.robust_chi2 = keepChi;
+            if (gpuSchur) {
+                MslamRuntime::check(mslam_ba_plan_set_state(plan, poses.data(), nullptr), "mslam_ba_plan_set_state");
+                tempChi = chi2_only();                                  // computeActiveErrors + activeRobustChi2
+                for (int j = 0; j < n6; j++) scale += x[(size_t)j] * (lambda * x[(size_t)j] + s.b[(size_t)j]);
+            } else {
+                for (int i = 0; i < 3 * s.npts; i++) points[(size_t)i] += x[(size_t)6 * s.nf + i];
+                const double keepChi = s.robust_chi2;
+                linearise(false);
+                tempChi = s.robust_chi2;
+                s.robust_chi2 = keepChi;
+                for (int j = 0; j < (poseOnly ? n6 : nx); j++) scale += x[(size_t)j] * (lambda * x[(size_t)j] + s.b[(size_t)j]);
+            }
+            if (!ok2) tempChi = DBL_MAX;
             rho = currentChi - tempChi;
-            double scale = 0;
-            for (int j = 0; j < (poseOnly ? 6 * s.nf : nx); j++) scale += x[(size_t)j] * (lambda * x[(size_t)j] + s.b[(size_t)j]);
             scale += 1e-3;
             rho /= scale;
             if (rho > 0 && std::isfinite(tempChi)) {
@@ -246,11 +271,17 @@ void Util::runBA(DataManager& data, std::vector<Frame>& frames, std::vector<MapP
                 ni = 2; currentChi = tempChi;
             } else {
                 lambda *= ni; ni *= 2;
-                poses = bkPoses; points = bkPoints;                    // pop
+                poses = bkPoses;                                        // pop
+                if (gpuSchur) {
+                    MslamRuntime::check(mslam_ba_plan_points_snapshot_dev(plan, 1), "points_restore");
+                    MslamRuntime::check(mslam_ba_plan_set_state(plan, poses.data(), nullptr), "mslam_ba_plan_set_state");
+                    if (rho < 0 && qmax + 1 < 10) (void)chi2_only();    // re-linearise at the restored state for the next trial
+                } else points = bkPoints;
             }
             qmax++;
         } while (rho < 0 && qmax < 10);
         lastChi2History.push_back(currentChi);
+        if (gpuSchur) MslamRuntime::check(mslam_ba_plan_get_state(plan, nullptr, points.data()), "mslam_ba_plan_get_state");
         if (qmax == 10 || rho == 0) break;
         if ((iniChi - currentChi) * 1e3 < iniChi) nBad++; else nBad = 0;
         if (nBad >= 3) break;

@@ -306,7 +306,7 @@ static int ldlt_solve(double* S, int n, const double* rhs, double* x)
 }
 
 /* BlockSolver::solve with Schur complement (block_solver.hpp:354-486) on a built system with lambda added */
-static int schur_solve(const orc_ba_system* s, int nf, int npts, double lambda, double* x)
+static int schur_solve(const orc_ba_system* s, int nf, int npts, double lambda, double* x, double* S_out, double* bs_out)
 {
     const int np6 = 6 * nf;
     double* S = (double*)calloc((size_t)np6 * np6 + 1, sizeof(double));
@@ -356,6 +356,10 @@ static int schur_solve(const orc_ba_system* s, int nf, int npts, double lambda, 
     }
     double* bs = (double*)malloc(sizeof(double) * (size_t)(np6 + 1));
     for (int a = 0; a < np6; a++) bs[a] = s->b[a] - coeff[a];
+    if (S_out) /* full symmetric matrix (the upper block triangle was accumulated) */
+        for (int a = 0; a < np6; a++)
+            for (int c = 0; c < np6; c++) S_out[a * np6 + c] = (a / 6 <= c / 6) ? S[a * np6 + c] : S[c * np6 + a];
+    if (bs_out) memcpy(bs_out, bs, sizeof(double) * (size_t)np6);
     ok = ldlt_solve(S, np6, bs, x);
     if (ok) { /* x_l = Dinv (b_l - Hpl^T x_p) */
         for (int i = 0; i < npts; i++) {
@@ -433,7 +437,7 @@ int orc_ba_optimize_ex(orc_ba_problem* p, double* poses, double* points, int ite
                 memset(x, 0, sizeof(double) * (size_t)nx);
                 ok2 = ldlt_solve(Hd, np6, s.b, x);
                 free(Hd);
-            } else ok2 = schur_solve(&s, nf, p->n_points, lambda, x);
+            } else ok2 = schur_solve(&s, nf, p->n_points, lambda, x, NULL, NULL);
             /* update (oplus) */
             for (int j = 0; j < p->n_poses; j++) if (fidx[j] >= 0) orc_se3_exp_left(x + 6 * fidx[j], poses + 7 * j);
             for (int i = 0; i < 3 * p->n_points; i++) points[i] += x[np6 + i];
@@ -467,4 +471,25 @@ int orc_ba_optimize_ex(orc_ba_problem* p, double* poses, double* points, int ite
     free(s.err); free(s.chi2); free(s.rho1); free(s.Hpp); free(s.Hll); free(s.Hpl_rowptr); free(s.Hpl_col); free(s.Hpl_val);
     free(s.b); free(x); free(bk_pose); free(bk_pts); free(fidx);
     return done;
+}
+
+/* one linearisation + Schur complement with `lambda` on every diagonal: S (6nf x 6nf), b_s (6nf), x (6nf + 3 n_points) */
+int orc_ba_schur(const orc_ba_problem* p, double lambda, double* S, double* bs, double* x)
+{
+    int nf = 0, nnzb = 0;
+    orc_ba_sizes(p, &nf, &nnzb);
+    orc_ba_system s;
+    s.err = (double*)malloc(sizeof(double) * 2 * (size_t)(p->n_edges + 1));
+    s.chi2 = (double*)malloc(sizeof(double) * (size_t)(p->n_edges + 1));
+    s.rho1 = (double*)malloc(sizeof(double) * (size_t)(p->n_edges + 1));
+    s.Hpp = (double*)malloc(sizeof(double) * 36 * (size_t)(nf + 1));
+    s.Hll = (double*)malloc(sizeof(double) * 9 * (size_t)(p->n_points + 1));
+    s.Hpl_rowptr = (int32_t*)malloc(sizeof(int32_t) * (size_t)(nf + 2));
+    s.Hpl_col = (int32_t*)malloc(sizeof(int32_t) * (size_t)(nnzb + 1));
+    s.Hpl_val = (double*)malloc(sizeof(double) * 18 * (size_t)(nnzb + 1));
+    s.b = (double*)malloc(sizeof(double) * (size_t)(6 * nf + 3 * p->n_points + 1));
+    orc_ba_build(p, &s);
+    int ok = schur_solve(&s, nf, p->n_points, lambda, x, S, bs);
+    free(s.err); free(s.chi2); free(s.rho1); free(s.Hpp); free(s.Hll); free(s.Hpl_rowptr); free(s.Hpl_col); free(s.Hpl_val); free(s.b);
+    return ok ? 0 : -6;
 }

@@ -248,3 +248,13 @@ def ba_optimize(pr, iterations: int, points_fixed: bool = False):
     lib().orc_ba_optimize_ex.restype = C.c_int
     done = lib().orc_ba_optimize_ex(C.byref(ps), _p(poses, f64p), _p(points, f64p), iterations, int(points_fixed), _p(hist, f64p), C.byref(nh))
     return dict(poses=poses, points=points, chi2=hist[: nh.value].copy(), iterations=done)
+
+
+def ba_schur(pr, lam: float):
+    ps, keep = _ba_problem_struct(pr)
+    nf, nnzb = C.c_int(0), C.c_int(0)
+    lib().orc_ba_sizes(C.byref(ps), C.byref(nf), C.byref(nnzb))
+    n6 = 6 * nf.value
+    S = np.zeros((n6, n6)); bs = np.zeros(n6); x = np.zeros(n6 + 3 * pr["n_points"])
+    rc = lib().orc_ba_schur(C.byref(ps), C.c_double(lam), _p(S, f64p), _p(bs, f64p), _p(x, f64p))
+    return dict(rc=rc, S=S, bs=bs, x=x)

@@ -132,6 +132,8 @@ void orc_se3quat_to_Rt(const double pose7[7], double Rt[12]);   /* Converter::SE
 void orc_se3_exp_left(const double delta6[6], double pose7[7]); /* T <- exp(delta) * T */
 /* full LM optimisation (OptimizationAlgorithmLevenberg + BlockSolver Schur), in place */
 int orc_ba_optimize(orc_ba_problem* p, double* poses, double* points, int iterations, double* chi2_history, int* n_hist);
+/* one linearisation + Schur complement (BlockSolver::solve): S (6nf x 6nf, full), b_s, x = (x_p, x_l) */
+int orc_ba_schur(const orc_ba_problem* p, double lambda, double* S, double* bs, double* x);
 /* points_fixed != 0: pose-only BA (Util::PoseBundleAdjustment, src/Util.cpp:222-358) */
 int orc_ba_optimize_ex(orc_ba_problem* p, double* poses, double* points, int iterations, int points_fixed, double* chi2_history, int* n_hist);
 

@@ -77,3 +77,34 @@ def test_invalid_problem(ctx):
     with pytest.raises(api.MslamError) as e:
         ctx.ba_build(pr)
     assert e.value.status == api.ERR_INVALID
+
+
+@pytest.mark.parametrize("n_poses,n_points,seed", [(10, 5000, 4004), (3, 40, 2), (25, 300, 3)])
+def test_schur_complement_and_back_substitution(ctx, oracle, n_poses, n_points, seed):
+    """f1: S, b_s on the device; x_p from a host solve; x_l by device back-substitution -- vs the oracle's BlockSolver::solve."""
+    pr = synth.ba_problem(n_poses, n_points, seed)
+    lam = 1e-5 * 1e6
+    o = oracle.ba_schur(pr, lam)
+    assert o["rc"] == 0
+    plan = api.BaPlan(ctx, pr)
+    plan.build_dev()
+    plan.schur_dev(lam)
+    S, bs = plan.download_schur()
+    scale = np.abs(o["S"]).max()
+    assert np.abs(S - o["S"]).max() <= 1e-9 * scale and np.abs(S - S.T).max() <= 1e-12 * scale
+    assert np.abs(bs - o["bs"]).max() <= 1e-9 * np.abs(o["bs"]).max()
+    xp = np.linalg.solve(S, bs)
+    n6 = 6 * plan.view.n_free_poses
+    np.testing.assert_allclose(xp, o["x"][:n6], rtol=1e-6, atol=1e-9 * np.abs(o["x"][:n6]).max())
+    p0, X0 = plan.get_state()
+    plan.points_snapshot_dev(False)
+    plan.backsub_dev(o["x"][:n6], apply_to_points=True)
+    x, sc = plan.download_x()
+    np.testing.assert_allclose(x[n6:], o["x"][n6:], rtol=1e-7, atol=1e-9 * np.abs(o["x"][n6:]).max())
+    b_l = plan.download()["b"][n6:]
+    assert abs(sc - np.sum(x[n6:] * (lam * x[n6:] + b_l))) <= 1e-9 * abs(sc)
+    p1, X1 = plan.get_state()
+    np.testing.assert_allclose(X1, X0 + x[n6:].reshape(-1, 3), rtol=0, atol=1e-15 * np.abs(X0).max() + 1e-15)
+    plan.points_snapshot_dev(True)
+    np.testing.assert_array_equal(plan.get_state()[1], X0)
+    plan.close()
