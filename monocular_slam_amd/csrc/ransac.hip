@@ -389,16 +389,16 @@ __device__ __forceinline__ bool fmat_inlier(const double* F, double u1, double v
         double d = x2tFx1 * x2tFx1 / (Fx1u * Fx1u + Fx1v * Fx1v + Ftx2u * Ftx2u + Ftx2v * Ftx2v);
         return fabs(d) < thr;
     }
-    double aa = F[0] * u1 + F[1] * v1 + F[2];
-    double bb = F[3] * u1 + F[4] * v1 + F[5];
-    double cc = F[6] * u1 + F[7] * v1 + F[8];
-    double s2 = 1. / (aa * aa + bb * bb);
-    double d2 = u2 * aa + v2 * bb + cc;
-    aa = F[0] * u2 + F[3] * v2 + F[6];
-    bb = F[1] * u2 + F[4] * v2 + F[7];
-    cc = F[2] * u2 + F[5] * v2 + F[8];
-    double s1 = 1. / (aa * aa + bb * bb);
-    double d1 = u1 * aa + v1 * bb + cc;
+    double aa = fma(F[0], u1, fma(F[1], v1, F[2]));
+    double bb = fma(F[3], u1, fma(F[4], v1, F[5]));
+    double cc = fma(F[6], u1, fma(F[7], v1, F[8]));
+    double s2 = 1. / fma(aa, aa, bb * bb);
+    double d2 = fma(u2, aa, fma(v2, bb, cc));
+    aa = fma(F[0], u2, fma(F[3], v2, F[6]));
+    bb = fma(F[1], u2, fma(F[4], v2, F[7]));
+    cc = fma(F[2], u2, fma(F[5], v2, F[8]));
+    double s1 = 1. / fma(aa, aa, bb * bb);
+    double d1 = fma(u1, aa, fma(v1, bb, cc));
     double e1 = d1 * d1 * s1, e2 = d2 * d2 * s2;
     return (double)(float)(e1 > e2 ? e1 : e2) <= thr; // err is stored as float by OpenCV
 }
@@ -448,16 +448,16 @@ void fmat_score_k(FmatArgs a)
                     cnt += __popcll(__ballot(in));
                 } else {
                     // same operations as fmat_inlier (OpenCV computeReprojError), divisions deferred behind the band test
-                    const double aa = F[0] * u1[j] + F[1] * v1[j] + F[2];
-                    const double bb = F[3] * u1[j] + F[4] * v1[j] + F[5];
-                    const double cc = F[6] * u1[j] + F[7] * v1[j] + F[8];
-                    const double n2 = aa * aa + bb * bb;
-                    const double d2 = u2[j] * aa + v2[j] * bb + cc;
-                    const double a2 = F[0] * u2[j] + F[3] * v2[j] + F[6];
-                    const double b2 = F[1] * u2[j] + F[4] * v2[j] + F[7];
-                    const double c2 = F[2] * u2[j] + F[5] * v2[j] + F[8];
-                    const double n1 = a2 * a2 + b2 * b2;
-                    const double d1 = u1[j] * a2 + v1[j] * b2 + c2;
+                    const double aa = fma(F[0], u1[j], fma(F[1], v1[j], F[2]));
+                    const double bb = fma(F[3], u1[j], fma(F[4], v1[j], F[5]));
+                    const double cc = fma(F[6], u1[j], fma(F[7], v1[j], F[8]));
+                    const double n2 = fma(aa, aa, bb * bb);
+                    const double d2 = fma(u2[j], aa, fma(v2[j], bb, cc));
+                    const double a2 = fma(F[0], u2[j], fma(F[3], v2[j], F[6]));
+                    const double b2 = fma(F[1], u2[j], fma(F[4], v2[j], F[7]));
+                    const double c2 = fma(F[2], u2[j], fma(F[5], v2[j], F[8]));
+                    const double n1 = fma(a2, a2, b2 * b2);
+                    const double d1 = fma(u1[j], a2, fma(v1[j], b2, c2));
                     const bool maybe = live[j] && (d2 * d2 <= thr_band * n2) && (d1 * d1 <= thr_band * n1);
                     if (__ballot(maybe)) { // wave-uniform
                         const double s2 = 1. / n2, s1 = 1. / n1;
@@ -681,10 +681,10 @@ struct PnpArgs {
 __device__ __forceinline__ void project_pt(const double* Rt, double fx, double fy, double cx, double cy, const double* k,
                                            bool has_dist, double X, double Y, double Z, double& u, double& v)
 {
-    // cvProjectPoints2
-    double x = Rt[0] * X + Rt[1] * Y + Rt[2] * Z + Rt[3];
-    double y = Rt[4] * X + Rt[5] * Y + Rt[6] * Z + Rt[7];
-    double z = Rt[8] * X + Rt[9] * Y + Rt[10] * Z + Rt[11];
+    // cvProjectPoints2; R X + t and the pixel mapping as explicit fma chains (same chains in the CPU restatement)
+    double x = fma(Rt[0], X, fma(Rt[1], Y, fma(Rt[2], Z, Rt[3])));
+    double y = fma(Rt[4], X, fma(Rt[5], Y, fma(Rt[6], Z, Rt[7])));
+    double z = fma(Rt[8], X, fma(Rt[9], Y, fma(Rt[10], Z, Rt[11])));
     z = z ? 1. / z : 1;
     x *= z; y *= z;
     double xd = x, yd = y;
@@ -696,8 +696,8 @@ __device__ __forceinline__ void project_pt(const double* Rt, double fx, double f
         xd = x * cdist * icdist2 + k[2] * a1 + k[3] * a2;
         yd = y * cdist * icdist2 + k[2] * a3 + k[3] * a1;
     }
-    u = xd * fx + cx;
-    v = yd * fy + cy;
+    u = fma(xd, fx, cx);
+    v = fma(yd, fy, cy);
 }
 
 __global__ __launch_bounds__(256)
@@ -946,7 +946,7 @@ void pnp_solve_k(PnpArgs a)
             double u, v;
             project_pt(cand, K[0], K[4], K[2], K[5], k, has_dist, X4, Y4, Z4, u, v);
             double dx = u - ox, dy = v - oy;
-            double e = dx * dx + dy * dy;
+            double e = fma(dx, dx, dy * dy);
             if (e == e && (!have || e < beste)) {
                 have = true; beste = e;
 #pragma unroll
@@ -976,8 +976,9 @@ __device__ __forceinline__ void pnp_score_body(const PnpArgs& a, int b, int h0, 
     const double fx = K[0], fy = K[4], cx = K[2], cy = K[5];
     const double* Xw = a.X + (size_t)b * a.capP * 3;
     const double* x = a.x + (size_t)b * a.capP * 2;
+    const double thr_band = a.thr * (1.0 + 1e-6);
     for (int c0 = 0; c0 < P; c0 += SCORE_THREADS * PNP_PT) {
-        double X[PNP_PT], Y[PNP_PT], Z[PNP_PT], ox[PNP_PT], oy[PNP_PT];
+        double X[PNP_PT], Y[PNP_PT], Z[PNP_PT], ox[PNP_PT], oy[PNP_PT], ocx[PNP_PT], ocy[PNP_PT];
         bool live[PNP_PT];
 #pragma unroll
         for (int j = 0; j < PNP_PT; j++) {
@@ -986,6 +987,7 @@ __device__ __forceinline__ void pnp_score_body(const PnpArgs& a, int b, int h0, 
             const int ic = live[j] ? i : 0;
             X[j] = Xw[3 * ic]; Y[j] = Xw[3 * ic + 1]; Z[j] = Xw[3 * ic + 2];
             ox[j] = x[2 * ic]; oy[j] = x[2 * ic + 1];
+            ocx[j] = ox[j] - cx; ocy[j] = oy[j] - cy;
         }
         for (int q = 0; q < nh; q++) {
             if (!s_valid[q]) continue; // wave-uniform
@@ -1000,23 +1002,23 @@ __device__ __forceinline__ void pnp_score_body(const PnpArgs& a, int b, int h0, 
                     project_pt(Rt, fx, fy, cx, cy, k, true, X[j], Y[j], Z[j], u, v);
                     const double dx = ox[j] - u, dy = oy[j] - v;
                     // sqrt(d2) < thr  <=>  d2 < thr2cut  (thr2cut = smallest double whose sqrt is >= thr)
-                    const bool in = live[j] && (dx * dx + dy * dy < a.thr2cut);
+                    const bool in = live[j] && (fma(dx, dx, dy * dy) < a.thr2cut);
                     cnt += __popcll(__ballot(in));
                 } else {
                     // Without distortion an inlier needs |fx*px - (ox-cx)*pz| < thr*|pz| (and the same in y).  This
                     // division-free band test (with a 1e-6 relative safety margin: a strict superset of the exact
                     // rule) rejects almost every point of a wrong hypothesis; only when some lane of the wavefront
                     // passes is the exact cvProjectPoints2 evaluation (same operations as project_pt) carried out.
-                    const double px = Rt[0] * X[j] + Rt[1] * Y[j] + Rt[2] * Z[j] + Rt[3];
-                    const double py = Rt[4] * X[j] + Rt[5] * Y[j] + Rt[6] * Z[j] + Rt[7];
-                    const double pz = Rt[8] * X[j] + Rt[9] * Y[j] + Rt[10] * Z[j] + Rt[11];
-                    const double band = a.thr * (1.0 + 1e-6) * fabs(pz);
-                    const bool maybe = live[j] && ((pz == 0.0) | ((fabs(fx * px - (ox[j] - cx) * pz) <= band) & (fabs(fy * py - (oy[j] - cy) * pz) <= band)));
+                    const double px = fma(Rt[0], X[j], fma(Rt[1], Y[j], fma(Rt[2], Z[j], Rt[3])));
+                    const double py = fma(Rt[4], X[j], fma(Rt[5], Y[j], fma(Rt[6], Z[j], Rt[7])));
+                    const double pz = fma(Rt[8], X[j], fma(Rt[9], Y[j], fma(Rt[10], Z[j], Rt[11])));
+                    const double band = thr_band * fabs(pz);
+                    const bool maybe = live[j] && ((pz == 0.0) | ((fabs(fma(fx, px, -(ocx[j] * pz))) <= band) & (fabs(fma(fy, py, -(ocy[j] * pz))) <= band)));
                     if (__ballot(maybe)) { // wave-uniform
                         double z = pz ? 1. / pz : 1;
-                        const double u = (px * z) * fx + cx, v = (py * z) * fy + cy;
+                        const double u = fma(px * z, fx, cx), v = fma(py * z, fy, cy);
                         const double dx = ox[j] - u, dy = oy[j] - v;
-                        const bool in = maybe && (dx * dx + dy * dy < a.thr2cut);
+                        const bool in = maybe && (fma(dx, dx, dy * dy) < a.thr2cut);
                         cnt += __popcll(__ballot(in));
                     }
                 }
@@ -1109,7 +1111,7 @@ void pnp_finalize_k(PnpArgs a)
         double u, v;
         project_pt(s_Rt, fx, fy, cx, cy, k, has_dist, Xw[3 * i], Xw[3 * i + 1], Xw[3 * i + 2], u, v);
         double dx = x[2 * i] - u, dy = x[2 * i + 1] - v;
-        bool in = dx * dx + dy * dy < a.thr2cut;
+        bool in = fma(dx, dx, dy * dy) < a.thr2cut;
         mask[i] = (uint8_t)in;
         my += in;
     }

@@ -22,6 +22,11 @@
  */
 #include "oracle.h"
 #include <float.h>
+#if defined(__x86_64__) && defined(__GNUC__)
+#define ORC_FMA_CLONES __attribute__((target_clones("fma", "default")))
+#else
+#define ORC_FMA_CLONES
+#endif
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -139,7 +144,9 @@ int orc_fmat_8point_normalized(const double* x1, const double* x2, const int32_t
     return 0;
 }
 
-/* metric 0: getInlier's Sampson distance (:715-763); metric 1: OpenCV computeReprojError */
+/* metric 0: getInlier's Sampson distance (:715-763); metric 1: OpenCV computeReprojError, its line products and
+ * norms evaluated as explicit fma chains (exact IEEE fma: identical on CPU and GPU) */
+ORC_FMA_CLONES
 double orc_fmat_error(const double F[9], const double* p1, const double* p2, int metric)
 {
     double u1 = p1[0], v1 = p1[1], u2 = p2[0], v2 = p2[1];
@@ -153,16 +160,16 @@ double orc_fmat_error(const double F[9], const double* p1, const double* p2, int
         double d = x2tFx1 * x2tFx1 / (Fx1u * Fx1u + Fx1v * Fx1v + Ftx2u * Ftx2u + Ftx2v * Ftx2v);
         return fabs(d);
     }
-    double a = F[0] * u1 + F[1] * v1 + F[2];
-    double b = F[3] * u1 + F[4] * v1 + F[5];
-    double c = F[6] * u1 + F[7] * v1 + F[8];
-    double s2 = 1. / (a * a + b * b);
-    double d2 = u2 * a + v2 * b + c;
-    a = F[0] * u2 + F[3] * v2 + F[6];
-    b = F[1] * u2 + F[4] * v2 + F[7];
-    c = F[2] * u2 + F[5] * v2 + F[8];
-    double s1 = 1. / (a * a + b * b);
-    double d1 = u1 * a + v1 * b + c;
+    double a = fma(F[0], u1, fma(F[1], v1, F[2]));
+    double b = fma(F[3], u1, fma(F[4], v1, F[5]));
+    double c = fma(F[6], u1, fma(F[7], v1, F[8]));
+    double s2 = 1. / fma(a, a, b * b);
+    double d2 = fma(u2, a, fma(v2, b, c));
+    a = fma(F[0], u2, fma(F[3], v2, F[6]));
+    b = fma(F[1], u2, fma(F[4], v2, F[7]));
+    c = fma(F[2], u2, fma(F[5], v2, F[8]));
+    double s1 = 1. / fma(a, a, b * b);
+    double d1 = fma(u1, a, fma(v1, b, c));
     double e1 = d1 * d1 * s1, e2 = d2 * d2 * s2;
     return (double)(float)(e1 > e2 ? e1 : e2);
 }

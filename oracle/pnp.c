@@ -25,6 +25,12 @@
  */
 #include "oracle.h"
 #include <float.h>
+/* hot loops with explicit fma(): build a hardware-FMA clone and a portable one, picked at load time */
+#if defined(__x86_64__) && defined(__GNUC__)
+#define ORC_FMA_CLONES __attribute__((target_clones("fma", "default")))
+#else
+#define ORC_FMA_CLONES
+#endif
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -53,12 +59,15 @@ void orc_undistort_normalize(const double* x, int n, const double K[9], const do
     }
 }
 
-/* cvProjectPoints2 for one point */
+/* cvProjectPoints2 for one point.  The three rows of R X + t and the final pixel mapping are evaluated as explicit
+ * fused multiply-add chains (one of the evaluations a contracting compiler produces for OpenCV's expressions; exact
+ * IEEE fma, so CPU and GPU agree bit for bit); everything else is plain source-order arithmetic. */
+ORC_FMA_CLONES
 void orc_project(const double Rt[12], const double K[9], const double k[8], const double X[3], double uv[2])
 {
-    double x = Rt[0] * X[0] + Rt[1] * X[1] + Rt[2] * X[2] + Rt[3];
-    double y = Rt[4] * X[0] + Rt[5] * X[1] + Rt[6] * X[2] + Rt[7];
-    double z = Rt[8] * X[0] + Rt[9] * X[1] + Rt[10] * X[2] + Rt[11];
+    double x = fma(Rt[0], X[0], fma(Rt[1], X[1], fma(Rt[2], X[2], Rt[3])));
+    double y = fma(Rt[4], X[0], fma(Rt[5], X[1], fma(Rt[6], X[2], Rt[7])));
+    double z = fma(Rt[8], X[0], fma(Rt[9], X[1], fma(Rt[10], X[2], Rt[11])));
     z = z ? 1. / z : 1;
     x *= z; y *= z;
     double r2 = x * x + y * y, r4 = r2 * r2, r6 = r4 * r2;
@@ -67,8 +76,8 @@ void orc_project(const double Rt[12], const double K[9], const double k[8], cons
     double icdist2 = 1. / (1 + k[5] * r2 + k[6] * r4 + k[7] * r6);
     double xd = x * cdist * icdist2 + k[2] * a1 + k[3] * a2;
     double yd = y * cdist * icdist2 + k[2] * a3 + k[3] * a1;
-    uv[0] = xd * K[0] + K[2];
-    uv[1] = yd * K[4] + K[5];
+    uv[0] = fma(xd, K[0], K[2]);
+    uv[1] = fma(yd, K[4], K[5]);
 }
 
 void orc_rodrigues_to_R(const double r[3], double R[9])
@@ -295,13 +304,14 @@ int orc_pnp_hypothesis(const double* X, const double* xn, const double* x, const
         for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) cand[i * 4 + j] = R[c][i * 3 + j]; cand[i * 4 + 3] = t[c][i]; }
         orc_project(cand, K, dist, X + 3 * s[3], uv);
         double dx = uv[0] - x[2 * s[3]], dy = uv[1] - x[2 * s[3] + 1];
-        double e = dx * dx + dy * dy;
+        double e = fma(dx, dx, dy * dy);
         if (!(e == e)) continue; /* NaN */
         if (best < 0 || e < beste) { best = c; beste = e; memcpy(Rt, cand, sizeof(cand)); }
     }
     return best >= 0;
 }
 
+ORC_FMA_CLONES
 static int pnp_count(const double* X, const double* x, int P, const double K[9], const double dist[8],
                      const double Rt[12], double thr, uint8_t* mask)
 {
@@ -310,7 +320,7 @@ static int pnp_count(const double* X, const double* x, int P, const double K[9],
         double uv[2];
         orc_project(Rt, K, dist, X + 3 * i, uv);
         double dx = x[2 * i] - uv[0], dy = x[2 * i + 1] - uv[1];
-        int in = sqrt(dx * dx + dy * dy) < thr; /* norm(points[i] - projected[i]) < reprojectionError */
+        int in = sqrt(fma(dx, dx, dy * dy)) < thr; /* norm(points[i] - projected[i]) < reprojectionError */
         if (mask) mask[i] = (uint8_t)in;
         c += in;
     }
