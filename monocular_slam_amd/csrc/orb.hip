@@ -468,9 +468,11 @@ constexpr int DP_R = 21;               // raw patch radius: 18 (pattern reach) +
 constexpr int DP_N = 2 * DP_R + 1;     // 43
 constexpr int DP_PITCH = 52;           // LDS bytes per raw row (13 dwords: odd, so a column of rows is bank-conflict free)
 constexpr int DP_ROW_DW = 12;          // dwords actually loaded per row (45 bytes + misalignment)
-constexpr int HB_PITCH = 42;           // u16 per row of the horizontally blurred patch (21 dwords: odd)
 constexpr int DB_N = 37;               // blurred patch side (radius 18)
-constexpr int DB_PITCH = 40;
+constexpr int DH_RP = 22, DH_CG = 10;  // row pass: 22 row pairs x 10 groups of 4 columns (44 x 40 >= 43 x 37)
+constexpr int HT_DW = 23;              // dwords per column of the transposed row-pass result (46 u16 rows; odd)
+constexpr int DV_RG = 10;              // column pass: 10 groups of 4 rows per column
+constexpr int BT_DW = 11;              // dwords per column of the transposed blurred patch (44 u8 rows; odd)
 constexpr int DESC_WAVES = 4;
 
 __device__ __forceinline__ float fast_atan2_deg(float y, float x)
@@ -502,9 +504,9 @@ struct DescArgs {
 __global__ __launch_bounds__(64 * DESC_WAVES)
 void describe_k(OrbDev od, DescArgs out)
 {
-    __shared__ uint32_t s_raw[DESC_WAVES][DP_N * DP_PITCH / 4];
-    __shared__ uint16_t s_h[DESC_WAVES][DP_N * HB_PITCH];
-    __shared__ uint8_t s_blur[DESC_WAVES][DB_N * DB_PITCH];
+    __shared__ uint32_t s_raw[DESC_WAVES][2 * DH_RP * DP_PITCH / 4];
+    __shared__ uint32_t s_h[DESC_WAVES][4 * DH_CG * HT_DW];
+    __shared__ uint32_t s_blur[DESC_WAVES][DB_N * BT_DW];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int b = blockIdx.y;
     const int g = blockIdx.x * DESC_WAVES + wave; // keypoint index inside the frame
@@ -552,41 +554,69 @@ void describe_k(OrbDev od, DescArgs out)
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { m10 += __shfl_xor(m10, o); m01 += __shfl_xor(m01, o); }
     const float angle = fast_atan2_deg((float)m01, (float)m10);
-    // ---- separable 7x7 Gaussian of the patch: rows (43 x 37) then columns (37 x 37).  One output per lane and
-    // step: measured faster than longer per-lane runs (the kernel is VALU-bound, not LDS-bound).
-    uint16_t* hbuf = s_h[wave];
-    for (int i = lane; i < DP_N * DB_N; i += 64) {
-        int r = i / DB_N, c = i % DB_N; // output column c <-> raw column c+3 (centre), taps c..c+6
-        const uint8_t* p = raw + r * DP_PITCH + c;
-        int acc = 0;
+    // ---- separable 7x7 Gaussian of the patch with packed dot products (integer arithmetic: any association is exact).
+    // Rows: one item = 2 patch rows x 4 output columns; v_dot4_u32_u8 against the taps {18,34,49,55 | 49,34,18,0};
+    // the result is stored transposed (hT[col][row], u16) so that the column pass finds vertical neighbours packed
+    // in one dword for v_dot2_u32_u16.  Columns: one item = 1 column x 4 output rows, stored transposed as well
+    // (blurT[col][row], u8).  Rows/columns beyond 37 are scratch (computed from whatever LDS holds, never read back).
+    uint32_t* hT = s_h[wave];
+    {
+        const uint32_t GA = 18u | (34u << 8) | (49u << 16) | (55u << 24), GB = 49u | (34u << 8) | (18u << 16);
+        for (int i = lane; i < DH_RP * DH_CG; i += 64) {
+            const int rp = i / DH_CG, cg = i - rp * DH_CG;
+            uint32_t h[2][4];
 #pragma unroll
-        for (int j = 0; j < 7; j++) acc += c_gk[j] * p[j];
-        hbuf[r * HB_PITCH + c] = (uint16_t)acc; // <= 257*255 = 65535
+            for (int dr = 0; dr < 2; dr++) {
+                const uint32_t* q = raw32 + (2 * rp + dr) * (DP_PITCH / 4) + cg;
+                const uint32_t d0 = q[0], d1 = q[1], d2 = q[2], d3 = q[3];
+                const uint32_t e0 = __builtin_amdgcn_alignbyte(d1, d0, xo), e1 = __builtin_amdgcn_alignbyte(d2, d1, xo),
+                               e2 = __builtin_amdgcn_alignbyte(d3, d2, xo);
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const uint32_t A = k ? __builtin_amdgcn_alignbyte(e1, e0, k) : e0;
+                    const uint32_t Bv = k ? __builtin_amdgcn_alignbyte(e2, e1, k) : e1;
+                    h[dr][k] = __builtin_amdgcn_udot4(Bv, GB, __builtin_amdgcn_udot4(A, GA, 0u, false), false); // <= 65535
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) hT[(4 * cg + k) * HT_DW + rp] = h[0][k] | (h[1][k] << 16);
+        }
     }
     __syncthreads();
-    uint8_t* blur = s_blur[wave];
-    for (int i = lane; i < DB_N * DB_N; i += 64) {
-        int r = i / DB_N, c = i % DB_N;
-        int acc = 0;
-#pragma unroll
-        for (int j = 0; j < 7; j++) acc += c_gk[j] * (int)hbuf[(r + j) * HB_PITCH + c];
-        int v = (acc + (1 << 15)) >> 16;
-        blur[r * DB_PITCH + c] = (uint8_t)(v > 255 ? 255 : v);
+    uint32_t* blurT = s_blur[wave];
+    {
+        typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+        const us2 G01 = {18, 34}, G23 = {49, 55}, G45 = {49, 34}, G6l = {18, 0}, G6h = {0, 18};
+#define DOT2(P, G, C) __builtin_amdgcn_udot2(__builtin_bit_cast(us2, (P)), (G), (C), false)
+        for (int i = lane; i < DB_N * DV_RG; i += 64) {
+            const int rg = i / DB_N, c = i - rg * DB_N;
+            const uint32_t* q = hT + c * HT_DW + 2 * rg;
+            const uint32_t p0 = q[0], p1 = q[1], p2 = q[2], p3 = q[3], p4 = q[4];
+            const uint32_t q0 = __builtin_amdgcn_alignbyte(p1, p0, 2), q1 = __builtin_amdgcn_alignbyte(p2, p1, 2),
+                           q2 = __builtin_amdgcn_alignbyte(p3, p2, 2), q3 = __builtin_amdgcn_alignbyte(p4, p3, 2);
+            uint32_t o0 = DOT2(p3, G6l, DOT2(p2, G45, DOT2(p1, G23, DOT2(p0, G01, 1u << 15))));
+            uint32_t o1 = DOT2(q3, G6l, DOT2(q2, G45, DOT2(q1, G23, DOT2(q0, G01, 1u << 15))));
+            uint32_t o2 = DOT2(p4, G6l, DOT2(p3, G45, DOT2(p2, G23, DOT2(p1, G01, 1u << 15))));
+            uint32_t o3 = DOT2(p4, G6h, DOT2(q3, G45, DOT2(q2, G23, DOT2(q1, G01, 1u << 15))));
+            o0 = min(o0 >> 16, 255u); o1 = min(o1 >> 16, 255u); o2 = min(o2 >> 16, 255u); o3 = min(o3 >> 16, 255u);
+            blurT[c * BT_DW + rg] = o0 | (o1 << 8) | (o2 << 16) | (o3 << 24);
+        }
+#undef DOT2
     }
     __syncthreads();
     // ---- 256 rotated binary tests; test t = j*64 + lane, ballot j = descriptor bytes 8j..8j+7
     float ang = angle;
     ang *= (float)(3.1415926535897932384626433832795 / 180.f);
     const float ca = (float)cos((double)ang), sb = (float)sin((double)ang);
-    const uint8_t* centre = blur + 18 * DB_PITCH + 18;
+    const uint8_t* centre = reinterpret_cast<const uint8_t*>(blurT) + 18 * (BT_DW * 4) + 18; // [x][y]
     unsigned long long bits[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         const int8_t* pt = c_pattern + (j * 64 + lane) * 4;
         float x0 = pt[0] * ca - pt[1] * sb, y0 = pt[0] * sb + pt[1] * ca;
         float x1 = pt[2] * ca - pt[3] * sb, y1 = pt[2] * sb + pt[3] * ca;
-        int t0 = centre[__float2int_rn(y0) * DB_PITCH + __float2int_rn(x0)];
-        int t1 = centre[__float2int_rn(y1) * DB_PITCH + __float2int_rn(x1)];
+        int t0 = centre[__float2int_rn(x0) * (BT_DW * 4) + __float2int_rn(y0)];
+        int t1 = centre[__float2int_rn(x1) * (BT_DW * 4) + __float2int_rn(y1)];
         bits[j] = __ballot(t0 < t1);
     }
     if (!active) return;
