@@ -425,14 +425,16 @@ void fmat_score_k(FmatArgs a)
     if (tid < FM_HPB) s_cnt[tid] = 0;
     __syncthreads();
     const double4* pts = reinterpret_cast<const double4*>(a.pts + (size_t)b * a.capM * 4);
-    const double thr_band = a.thr * (1.0 + 1e-5);
+    const double thr_lo = a.thr * (1.0 - 1e-5), thr_hi = a.thr * (1.0 + 1e-5);
     for (int c0 = 0; c0 < M; c0 += SCORE_THREADS * FM_PT) {
         double u1[FM_PT], v1[FM_PT], u2[FM_PT], v2[FM_PT];
         bool live[FM_PT];
+        unsigned long long livem[FM_PT];
 #pragma unroll
         for (int j = 0; j < FM_PT; j++) {
             const int i = c0 + j * SCORE_THREADS + tid;
             live[j] = i < M;
+            livem[j] = __builtin_amdgcn_ballot_w64(live[j]);
             const double4 p = live[j] ? pts[i] : make_double4(0, 0, 0, 0);
             u1[j] = p.x; v1[j] = p.y; u2[j] = p.z; v2[j] = p.w;
         }
@@ -458,12 +460,18 @@ void fmat_score_k(FmatArgs a)
                     const double c2 = fma(F[2], u2[j], fma(F[5], v2[j], F[8]));
                     const double n1 = fma(a2, a2, b2 * b2);
                     const double d1 = fma(u1[j], a2, fma(v1[j], b2, c2));
-                    const bool maybe = live[j] && (d2 * d2 <= thr_band * n2) && (d1 * d1 <= thr_band * n1);
-                    if (__ballot(maybe)) { // wave-uniform
+                    // d^2 / n against thr without the divisions: decided by the sign outside a 1e-5 relative shell (the
+                    // exact rule differs from d^2 <= thr n only by the rounding of 1/n, two products and the float cast,
+                    // < 1e-7 relative); the shell, NaNs and nothing else take the exact evaluation.
+                    const double t1 = d1 * d1, t2 = d2 * d2;
+                    const unsigned long long din = __builtin_amdgcn_ballot_w64(t1 < thr_lo * n1) & __builtin_amdgcn_ballot_w64(t2 < thr_lo * n2); // strict: n == 0 (no model) stays undecided
+                    const unsigned long long dout = __builtin_amdgcn_ballot_w64(t1 > thr_hi * n1) | __builtin_amdgcn_ballot_w64(t2 > thr_hi * n2);
+                    const unsigned long long un = livem[j] & ~(din | dout);
+                    cnt += __popcll(din & livem[j]);
+                    if (un) { // wave-uniform, rare
                         const double s2 = 1. / n2, s1 = 1. / n1;
-                        const double e1 = d1 * d1 * s1, e2 = d2 * d2 * s2;
-                        const bool in = maybe && ((double)(float)(e1 > e2 ? e1 : e2) <= a.thr);
-                        cnt += __popcll(__ballot(in));
+                        const double e1 = t1 * s1, e2 = t2 * s2;
+                        cnt += __popcll(__builtin_amdgcn_ballot_w64((double)(float)(e1 > e2 ? e1 : e2) <= a.thr) & un);
                     }
                 }
             }
@@ -968,7 +976,7 @@ constexpr int PNP_PT = 8;
 
 template <bool HAS_DIST>
 __device__ __forceinline__ void pnp_score_body(const PnpArgs& a, int b, int h0, int nh, int tid, int lane, const double (*s_Rt)[12],
-                                               const int* s_valid, int* s_cnt)
+                                               const double (*s_Rs)[8], const double* s_tn, const int* s_valid, int* s_cnt)
 {
     const int P = a.P[b];
     const double* K = a.K + b * 9;
@@ -976,50 +984,83 @@ __device__ __forceinline__ void pnp_score_body(const PnpArgs& a, int b, int h0, 
     const double fx = K[0], fy = K[4], cx = K[2], cy = K[5];
     const double* Xw = a.X + (size_t)b * a.capP * 3;
     const double* x = a.x + (size_t)b * a.capP * 2;
-    const double thr_band = a.thr * (1.0 + 1e-6);
+    // Decision shell of the division-free test (see below).  A threshold too small for the error analysis to hold
+    // (or not finite) makes eps infinite/NaN, which sends every point down the exact path.
+    const double inv_thr = 1.0 / a.thr;
+    const double eps = (a.thr >= 1e-3 && a.thr <= 1e6) ? 1e-6 : __longlong_as_double(0x7ff0000000000000ll);
+    const double sf = (fabs(fx) > fabs(fy) ? fabs(fx) : fabs(fy)) * inv_thr;
     for (int c0 = 0; c0 < P; c0 += SCORE_THREADS * PNP_PT) {
         double X[PNP_PT], Y[PNP_PT], Z[PNP_PT], ox[PNP_PT], oy[PNP_PT], ocx[PNP_PT], ocy[PNP_PT];
         bool live[PNP_PT];
+        unsigned long long livem[PNP_PT];
+        double nrm = 0.0;
 #pragma unroll
         for (int j = 0; j < PNP_PT; j++) {
             const int i = c0 + j * SCORE_THREADS + tid;
             live[j] = i < P;
+            livem[j] = __builtin_amdgcn_ballot_w64(live[j]);
             const int ic = live[j] ? i : 0;
             X[j] = Xw[3 * ic]; Y[j] = Xw[3 * ic + 1]; Z[j] = Xw[3 * ic + 2];
             ox[j] = x[2 * ic]; oy[j] = x[2 * ic + 1];
-            ocx[j] = ox[j] - cx; ocy[j] = oy[j] - cy;
+            ocx[j] = (ox[j] - cx) * inv_thr; ocy[j] = (oy[j] - cy) * inv_thr; // threshold units
+            nrm = fmax(nrm, fabs(X[j]) + fabs(Y[j]) + fabs(Z[j]));
         }
         for (int q = 0; q < nh; q++) {
             if (!s_valid[q]) continue; // wave-uniform
-            double Rt[12];
-#pragma unroll
-            for (int e = 0; e < 12; e++) Rt[e] = s_Rt[q][e];
             int cnt = 0;
+            if (HAS_DIST) {
+                double Rt[12];
 #pragma unroll
-            for (int j = 0; j < PNP_PT; j++) {
-                if (HAS_DIST) {
+                for (int e = 0; e < 12; e++) Rt[e] = s_Rt[q][e];
+#pragma unroll
+                for (int j = 0; j < PNP_PT; j++) {
                     double u, v;
                     project_pt(Rt, fx, fy, cx, cy, k, true, X[j], Y[j], Z[j], u, v);
                     const double dx = ox[j] - u, dy = oy[j] - v;
                     // sqrt(d2) < thr  <=>  d2 < thr2cut  (thr2cut = smallest double whose sqrt is >= thr)
-                    const bool in = live[j] && (fma(dx, dx, dy * dy) < a.thr2cut);
-                    cnt += __popcll(__ballot(in));
-                } else {
-                    // Without distortion an inlier needs |fx*px - (ox-cx)*pz| < thr*|pz| (and the same in y).  This
-                    // division-free band test (with a 1e-6 relative safety margin: a strict superset of the exact
-                    // rule) rejects almost every point of a wrong hypothesis; only when some lane of the wavefront
-                    // passes is the exact cvProjectPoints2 evaluation (same operations as project_pt) carried out.
-                    const double px = fma(Rt[0], X[j], fma(Rt[1], Y[j], fma(Rt[2], Z[j], Rt[3])));
-                    const double py = fma(Rt[4], X[j], fma(Rt[5], Y[j], fma(Rt[6], Z[j], Rt[7])));
-                    const double pz = fma(Rt[8], X[j], fma(Rt[9], Y[j], fma(Rt[10], Z[j], Rt[11])));
-                    const double band = thr_band * fabs(pz);
-                    const bool maybe = live[j] && ((pz == 0.0) | ((fabs(fma(fx, px, -(ocx[j] * pz))) <= band) & (fabs(fma(fy, py, -(ocy[j] * pz))) <= band)));
-                    if (__ballot(maybe)) { // wave-uniform
-                        double z = pz ? 1. / pz : 1;
+                    cnt += __popcll(__builtin_amdgcn_ballot_w64(fma(dx, dx, dy * dy) < a.thr2cut) & livem[j]);
+                }
+            } else {
+                // Without distortion the reprojection error in threshold units is (A, B) / pz with
+                //   A = (fx/thr) (R0.X + t0) - ((ox-cx)/thr) pz,   B likewise in y,
+                // so  e = A^2 + B^2 - pz^2  is negative for an inlier.  Outside the shell |e| <= 1e-6 pz^2 the sign of e
+                // decides (the exact rule's own rounding is ~1e-12 relative there, provided pz is not tiny against the
+                // magnitudes it was formed from: |pz| >= 1e-7 (f/thr)(|X|_1 + |t|_1), which bounds the cancellation
+                // error of A/pz by ~1e-7).  Points inside the shell, with a tiny pz, or producing NaN take the exact
+                // cvProjectPoints2 evaluation (same operations as project_pt); they are ~1e-6 of all points.
+                double Rs[8], Rz[4];
+#pragma unroll
+                for (int e = 0; e < 8; e++) Rs[e] = s_Rs[q][e];
+#pragma unroll
+                for (int e = 0; e < 4; e++) Rz[e] = s_Rt[q][8 + e];
+                const double zg = 1e-7 * sf * (nrm + s_tn[q]) + 1e-300;
+                unsigned long long um[PNP_PT], any = 0; // undecided lanes per point slot
+#pragma unroll
+                for (int j = 0; j < PNP_PT; j++) {
+                    const double pxs = fma(Rs[0], X[j], fma(Rs[1], Y[j], fma(Rs[2], Z[j], Rs[3])));
+                    const double pys = fma(Rs[4], X[j], fma(Rs[5], Y[j], fma(Rs[6], Z[j], Rs[7])));
+                    const double pz = fma(Rz[0], X[j], fma(Rz[1], Y[j], fma(Rz[2], Z[j], Rz[3]))); // == project_pt's z
+                    const double A = fma(-ocx[j], pz, pxs), Bv = fma(-ocy[j], pz, pys);
+                    const double pz2 = pz * pz;
+                    const double e = fma(A, A, fma(Bv, Bv, -pz2));
+                    const double m = eps * pz2;
+                    const unsigned long long un = (__builtin_amdgcn_ballot_w64(!(fabs(e) > m)) | __builtin_amdgcn_ballot_w64(fabs(pz) < zg)) & livem[j];
+                    const unsigned long long in = __builtin_amdgcn_ballot_w64(e < -m) & livem[j] & ~un;
+                    cnt += __popcll(in);
+                    um[j] = un; any |= un;
+                }
+                if (any) { // wave-uniform, rare
+                    const double* Rt = s_Rt[q];
+#pragma unroll
+                    for (int j = 0; j < PNP_PT; j++) {
+                        if (!um[j]) continue;
+                        const double px = fma(Rt[0], X[j], fma(Rt[1], Y[j], fma(Rt[2], Z[j], Rt[3])));
+                        const double py = fma(Rt[4], X[j], fma(Rt[5], Y[j], fma(Rt[6], Z[j], Rt[7])));
+                        const double pz = fma(Rt[8], X[j], fma(Rt[9], Y[j], fma(Rt[10], Z[j], Rt[11])));
+                        const double z = pz ? 1. / pz : 1;
                         const double u = fma(px * z, fx, cx), v = fma(py * z, fy, cy);
                         const double dx = ox[j] - u, dy = oy[j] - v;
-                        const bool in = maybe && (fma(dx, dx, dy * dy) < a.thr2cut);
-                        cnt += __popcll(__ballot(in));
+                        cnt += __popcll(__builtin_amdgcn_ballot_w64(fma(dx, dx, dy * dy) < a.thr2cut) & um[j]);
                     }
                 }
             }
@@ -1034,21 +1075,31 @@ void pnp_score_k(PnpArgs a)
     const int b = blockIdx.y, h0 = blockIdx.x * PNP_HPB, tid = threadIdx.x, lane = tid & 63;
     const int nh = min(PNP_HPB, a.H - h0);
     __shared__ double s_Rt[PNP_HPB][12];
+    __shared__ double s_Rs[PNP_HPB][8]; // rows 0/1 scaled by fx/thr, fy/thr (division-free test only)
+    __shared__ double s_tn[PNP_HPB];
     __shared__ int s_cnt[PNP_HPB];
     __shared__ int s_valid[PNP_HPB];
-    for (int i = tid; i < PNP_HPB * 12; i += SCORE_THREADS) {
-        const int hh = i / 12, e = i % 12;
-        s_Rt[hh][e] = (hh < nh) ? a.models[((size_t)b * a.H + h0 + hh) * 12 + e] : 0.0;
+    {
+        const double* K = a.K + b * 9;
+        const double sfx = K[0] / a.thr, sfy = K[4] / a.thr;
+        for (int i = tid; i < PNP_HPB * 12; i += SCORE_THREADS) {
+            const int hh = i / 12, e = i % 12;
+            const double v = (hh < nh) ? a.models[((size_t)b * a.H + h0 + hh) * 12 + e] : 0.0;
+            s_Rt[hh][e] = v;
+            if (e < 8) s_Rs[hh][e] = v * (e < 4 ? sfx : sfy);
+        }
     }
     if (tid < PNP_HPB) s_cnt[tid] = 0;
     __syncthreads();
-    if (tid < PNP_HPB) // a hypothesis without a pose is all zero (row 2 of a rotation cannot be zero)
+    if (tid < PNP_HPB) { // a hypothesis without a pose is all zero (row 2 of a rotation cannot be zero)
         s_valid[tid] = !(s_Rt[tid][8] == 0.0 && s_Rt[tid][9] == 0.0 && s_Rt[tid][10] == 0.0);
+        s_tn[tid] = fabs(s_Rt[tid][3]) + fabs(s_Rt[tid][7]) + fabs(s_Rt[tid][11]);
+    }
     __syncthreads();
     const double* k = a.dist + b * 8;
     const bool has_dist = (k[0] != 0.0) | (k[1] != 0.0) | (k[2] != 0.0) | (k[3] != 0.0) | (k[4] != 0.0) | (k[5] != 0.0) | (k[6] != 0.0) | (k[7] != 0.0);
-    if (has_dist) pnp_score_body<true>(a, b, h0, nh, tid, lane, s_Rt, s_valid, s_cnt);
-    else pnp_score_body<false>(a, b, h0, nh, tid, lane, s_Rt, s_valid, s_cnt);
+    if (has_dist) pnp_score_body<true>(a, b, h0, nh, tid, lane, s_Rt, s_Rs, s_tn, s_valid, s_cnt);
+    else pnp_score_body<false>(a, b, h0, nh, tid, lane, s_Rt, s_Rs, s_tn, s_valid, s_cnt);
     __syncthreads();
     if (tid < nh) a.counts[(size_t)b * a.H + h0 + tid] = s_valid[tid] ? s_cnt[tid] : 0;
 }
