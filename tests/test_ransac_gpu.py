@@ -158,3 +158,67 @@ def test_triangulate_matches_oracle(ctx, oracle):
     _, fo2, no2 = oracle.triangulate(tv["x1"], tv["x2"], Rt1, Rt2b, tv["K"], tv["K"])
     np.testing.assert_array_equal(fg2, fo2)
     assert ng2 == no2 and ng2 < 300
+
+
+def test_pnp_threshold_shell_and_camera_plane(ctx, oracle):
+    """The division-free inlier test must hand every undecided point to the exact rule: observations placed at
+    thr * (1 +- tiny) from the noise-free projection, world points on (and next to) the camera plane z = 0."""
+    pr = synth.pnp_problem(600, 41, noise=0.0, outlier_frac=0.1)
+    X, x, K, R, t = pr["X"].copy(), pr["x"].copy(), pr["K"], pr["R"], pr["tvec"]
+    thr = 2.0
+    rng = np.random.default_rng(5)
+    good = np.flatnonzero(~pr["outlier"])
+    deltas = np.array([0.0, 1e-15, -1e-15, 1e-12, -1e-12, 1e-9, -1e-9, 1e-7, -1e-7, 1e-6, -1e-6, 1e-5, -1e-5])
+    for n, i in enumerate(good[:260]):
+        a = rng.uniform(0, 2 * np.pi)
+        Xc = R @ X[i] + t
+        proj = np.array([K[0, 0] * Xc[0] / Xc[2] + K[0, 2], K[1, 1] * Xc[1] / Xc[2] + K[1, 2]])
+        x[i] = proj + thr * (1 + deltas[n % len(deltas)]) * np.array([np.cos(a), np.sin(a)])
+    for n, i in enumerate(good[260:300]):  # points on / next to the camera plane of the true pose
+        zc = [0.0, 1e-300, -1e-18, 1e-14, -1e-12, 1e-10, 1e-8, -1e-6][n % 8]
+        X[i] = R.T @ (np.array([rng.uniform(-1, 1), rng.uniform(-1, 1), zc]) - t)
+    S = synth.sample_table(600, 512, 4, 9)
+    S[:48] = rng.permutation(good[300:])[:192].reshape(48, 4)  # all-inlier samples: poses equal to the truth up to rounding
+    p = api.default_pnp_params()
+    p.reproj_thr, p.confidence = thr, 0.0
+    g = ctx.pnp_ransac(X, x, K, pr["dist"], S, p)
+    o = oracle.pnp_ransac(X, x, K, pr["dist"], S, _pp(oracle, p))
+    assert g["rc"] == 0 and o["rc"] == 0
+    np.testing.assert_array_equal(g["counts"], o["counts"])
+    np.testing.assert_array_equal(g["inliers"], o["inliers"])
+    assert g["best_h"] == o["best_h"]
+    # an identity pose with points exactly on z = 0 (projectPoints' z ? 1/z : 1 quirk) through the scoring path
+    X0 = np.zeros((8, 3)); X0[:, :2] = rng.uniform(-1, 1, (8, 2)); X0[4:, 2] = rng.uniform(2, 4, 4)
+    x0 = np.stack([K[0, 0] * X0[:, 0] + K[0, 2], K[1, 1] * X0[:, 1] + K[1, 2]], axis=1)  # what z -> 1 projects to
+    x0[4:] = np.stack([K[0, 0] * X0[4:, 0] / X0[4:, 2] + K[0, 2], K[1, 1] * X0[4:, 1] / X0[4:, 2] + K[1, 2]], axis=1)
+    S0 = np.array([[4, 5, 6, 7]], np.int32)
+    p.min_inliers = 1
+    g = ctx.pnp_ransac(X0, x0, K, np.zeros(8), S0, p)
+    o = oracle.pnp_ransac(X0, x0, K, np.zeros(8), S0, _pp(oracle, p))
+    np.testing.assert_array_equal(g["counts"], o["counts"])
+    np.testing.assert_array_equal(g["inliers"], o["inliers"])
+
+
+def test_fmat_threshold_shell(ctx, oracle):
+    """Matches displaced from their epipolar line by sqrt(thr) * (1 +- tiny): counts and masks still bit-exact."""
+    tv = synth.two_view_problem(400, 31, noise=0.0, outlier_frac=0.1)
+    x1, x2, K, R, t = tv["x1"].copy(), tv["x2"].copy(), tv["K"], tv["R"], tv["t"]
+    tx = np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]])
+    Ki = np.linalg.inv(K)
+    F = Ki.T @ tx @ R @ Ki
+    thr = 3.0
+    good = np.flatnonzero(~tv["outlier"])
+    deltas = np.array([0.0, 1e-15, -1e-15, 1e-12, -1e-12, 1e-9, -1e-9, 1e-7, -1e-7, 3e-6, -3e-6, 1e-4, -1e-4])
+    for n, i in enumerate(good[:200]):
+        l2 = F @ np.array([x1[i, 0], x1[i, 1], 1.0])
+        nrm = l2[:2] / np.hypot(l2[0], l2[1])
+        x2[i] = x2[i] + np.sqrt(thr) * (1 + deltas[n % len(deltas)]) * nrm
+    S = synth.sample_table(400, 256, 8, 4)
+    S[:12] = np.random.default_rng(2).permutation(good[200:])[:96].reshape(12, 8)
+    p = api.default_fmat_params()
+    p.threshold, p.confidence = thr, 0.0
+    g = ctx.fmat_ransac8(x1, x2, S, p)
+    o = oracle.fmat_ransac8(x1, x2, S, _fp(oracle, p))
+    np.testing.assert_array_equal(g["counts"], o["counts"])
+    np.testing.assert_array_equal(g["status"], o["status"])
+    assert g["best_h"] == o["best_h"]
