@@ -52,6 +52,8 @@ constexpr int FT_W = FS_W - 2, FT_H = FS_H - 2;   // outputs per tile (126 x 30)
 constexpr int FP_H = FS_H + 6;                    // pixel tile rows (38)
 constexpr int FP_PITCH = 136;                     // LDS row pitch in bytes (34 dwords: 134 columns + 2 pad)
 constexpr int FAST_THREADS = 256;
+constexpr int CNT_STRIDE = 32;                    // candidate counters one per 128-byte line: tiles of different
+                                                  // (frame, level) pairs must not serialise on one L2 atomic unit
 
 struct LevelDesc {
     uint8_t* img; int w, h, pitch; long long frame_stride; // bytes
@@ -315,8 +317,8 @@ void fast_nms_k(OrbDev od)
     }
     __syncthreads();
     const int ne = s_ne;
-    if (ne == 0) return;
-    if (tid == 0) s_base = (int)atomicAdd(&od.cnt[b * od.L + l], (uint32_t)ne);
+    if (ne == 0 || od.ablate == 4) return;
+    if (tid == 0) s_base = (int)atomicAdd(&od.cnt[(b * od.L + l) * CNT_STRIDE], (uint32_t)ne);
     __syncthreads();
     uint32_t* cand = lv.cand + (size_t)b * lv.cand_cap;
     for (int j = tid; j < ne; j += FAST_THREADS)
@@ -368,7 +370,7 @@ void select_k(OrbDev od)
     const int l = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
     const LevelDesc& lv = od.lv[l];
     const uint8_t* img = lv.img + b * lv.frame_stride;
-    const int ncand = min((int)od.cnt[b * od.L + l], lv.cand_cap);
+    const int ncand = min((int)od.cnt[(b * od.L + l) * CNT_STRIDE], lv.cand_cap);
     const uint32_t* cand = lv.cand + (size_t)b * lv.cand_cap;
     uint32_t* candA = lv.candA + (size_t)b * lv.cand_cap;
     float* respA = lv.respA + (size_t)b * lv.cand_cap;
@@ -523,7 +525,10 @@ void describe_k(OrbDev od, DescArgs out)
         out.n_out[b] = bad ? 0 : total;
         if (out.status) out.status[b] = bad ? (int)MSLAM_ERR_CAPACITY : (int)MSLAM_OK;
     }
-    const bool active = !bad && l >= 0; // wave-uniform; inactive waves still reach the barriers
+    // blocks entirely beyond the keypoint count have nothing to do (the grid is sized for the capacity); the condition is
+    // uniform over the block, so no barrier is skipped by part of it
+    if (blockIdx.x > 0 && (bad || blockIdx.x * DESC_WAVES >= total)) return;
+    const bool active = !bad && l >= 0; // wave-uniform; inactive waves of a partial block still reach the barriers
     if (l < 0) l = 0;
     const LevelDesc& lv = od.lv[l];
     const uint2 sel = active ? od.sel[((size_t)b * od.L + l) * od.max_kpts + (g - off)] : make_uint2((DP_R << 12) | DP_R, 0);
@@ -765,14 +770,14 @@ static int orb_plan_get(mslam_ctx* ctx, int w, int h, int B, int channels, const
     od.tiles_per_frame = tile_base;
     const size_t off_sel = reserve(sizeof(uint2) * (size_t)B * L * od.max_kpts);
     const size_t n_cnt = (size_t)B * L;
-    pl->counters_bytes = sizeof(uint32_t) * (2 * n_cnt + B);
+    pl->counters_bytes = sizeof(uint32_t) * ((CNT_STRIDE + 1) * n_cnt + B);
     const size_t off_cnt = reserve(pl->counters_bytes);
     HIP_TRY(ctx, hipMalloc(&pl->arena, bytes));
     pl->arena_bytes = bytes;
     char* base = (char*)pl->arena;
     pl->counters = (uint32_t*)(base + off_cnt);
     od.cnt = pl->counters;
-    od.sel_cnt = (int32_t*)(od.cnt + n_cnt);
+    od.sel_cnt = (int32_t*)(od.cnt + CNT_STRIDE * n_cnt);
     od.frame_status = od.sel_cnt + n_cnt;
     od.sel = (uint2*)(base + off_sel);
     std::vector<int4> tab;
