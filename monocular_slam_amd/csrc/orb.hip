@@ -193,8 +193,10 @@ void fast_nms_k(OrbDev od)
     __shared__ uint32_t s_pix[FP_H * FP_PITCH / 4];
     __shared__ uint8_t s_score[FS_H * FS_W];
     __shared__ uint16_t s_list[FS_H * FS_W];
-    __shared__ uint32_t s_emit[(FT_W / 2) * (FT_H / 2) + 64];
     __shared__ int s_n1, s_ne, s_base;
+    // NMS maxima (<= 63 x 15 per tile) are collected in the pixel tile's storage, which is dead after phase 2
+    uint32_t* s_emit = s_pix;
+    static_assert(((FT_W + 1) / 2) * ((FT_H + 1) / 2) * 4 <= FP_H * FP_PITCH, "emit buffer must fit in the pixel tile");
 
     // tile -> (frame, level, tx, ty): blocks of one frame are consecutive
     const int b = blockIdx.x / od.tiles_per_frame;
@@ -211,17 +213,28 @@ void fast_nms_k(OrbDev od)
     if (tid == 0) { s_n1 = 0; s_ne = 0; }
     for (int i = tid; i < FS_H * FS_W / 4; i += FAST_THREADS) reinterpret_cast<uint32_t*>(s_score)[i] = 0;
     // ---- stage the pixel tile: LDS dword j of row r = image bytes x = (ox - 5 + 4j) .. +3 of row (oy - 4 + r),
-    // assembled from two aligned global dwords with v_alignbyte (the tile origin is not dword aligned)
+    // assembled from two aligned global dwords with v_alignbyte (the tile origin is not dword aligned).  A half
+    // wavefront takes dwords 0..31 of one row (8 rows per pass); the two remaining dwords of every row go last.
     {
         const int gx0 = ox - 5;                 // >= 17 (edge >= 22)
         const int sh = gx0 & 3, a0 = gx0 >> 2;
-        const int max_dw = lv.pitch / 4 - 1;
-        for (int i = tid; i < FP_H * (FP_PITCH / 4); i += FAST_THREADS) {
-            const int r = i / (FP_PITCH / 4), j = i - r * (FP_PITCH / 4);
-            const int gy = min(oy - 4 + r, lv.h - 1);
-            const uint32_t* row = reinterpret_cast<const uint32_t*>(img + (size_t)gy * lv.pitch);
-            const uint32_t lo = row[min(a0 + j, max_dw)], hi = row[min(a0 + j + 1, max_dw)];
-            s_pix[i] = __builtin_amdgcn_alignbyte(hi, lo, sh);
+        const int max_dw = lv.pitch / 4 - 1, pitch_dw = lv.pitch / 4;
+        const uint32_t* img32 = reinterpret_cast<const uint32_t*>(img);
+        static_assert(FP_PITCH / 4 == 34, "staging assumes 32 + 2 dwords per row");
+        const int j = tid & 31;
+        const int c0 = min(a0 + j, max_dw), c1 = min(a0 + j + 1, max_dw);
+#pragma unroll
+        for (int r0 = 0; r0 < FP_H; r0 += FAST_THREADS / 32) {
+            const int r = r0 + (tid >> 5);
+            if (r < FP_H) {
+                const int rowo = min(oy - 4 + r, lv.h - 1) * pitch_dw;
+                s_pix[r * (FP_PITCH / 4) + j] = __builtin_amdgcn_alignbyte(img32[rowo + c1], img32[rowo + c0], sh);
+            }
+        }
+        if (tid < 2 * FP_H) {
+            const int r = tid >> 1, jj = 32 + (tid & 1);
+            const int rowo = min(oy - 4 + r, lv.h - 1) * pitch_dw;
+            s_pix[r * (FP_PITCH / 4) + jj] = __builtin_amdgcn_alignbyte(img32[rowo + min(a0 + jj + 1, max_dw)], img32[rowo + min(a0 + jj, max_dw)], sh);
         }
     }
     __syncthreads();
@@ -230,45 +243,44 @@ void fast_nms_k(OrbDev od)
     // score (sx, sy) <-> image pixel (ox - 1 + sx, oy - 1 + sy) <-> LDS byte (sy + 3) * FP_PITCH + sx + 4
     const int lim_x = min(FS_W, lv.roi_x0 + lv.roi_w + 1 - (ox - 1)); // scores only needed up to ROI + 1
     const int lim_y = min(FS_H, lv.roi_y0 + lv.roi_h + 1 - (oy - 1));
-    // ---- phase 1: high-speed rejection on 4 pixels per lane from 5 dword reads
-    // (an arc of 9 contains ring pixel 0 or 8, and 4 or 12)
+    // ---- phase 1: high-speed rejection on 4 pixels per lane from 5 dword reads: an arc of 9 equal-polarity ring
+    // pixels contains pixel 0 or 8 AND pixel 4 or 12 of that polarity.  All predicates are wavefront lane masks
+    // (v_cmp -> SGPR pair, logic on the scalar unit); the survivors are appended to s_list by ballot compaction.
+    const int lane = tid & 63;
+    const unsigned long long below = (1ull << lane) - 1ull;
     {
         const int g = tid & 31, ry = tid >> 5;
 #pragma unroll
         for (int m = 0; m < FS_H / 8; m++) {
             const int sy = ry + 8 * m;
-            uint32_t pm = 0; // pass mask of this lane's 4 pixels
-            if (sy < lim_y && 4 * g < lim_x) {
-                const uint32_t* rowp = s_pix + (sy + 3) * (FP_PITCH / 4) + g;
-                const uint32_t Lw = rowp[0], Cw = rowp[1], Rw = rowp[2];
-                const uint32_t Tw = rowp[1 - 3 * (FP_PITCH / 4)], Bw = rowp[1 + 3 * (FP_PITCH / 4)];
-                const uint32_t P4 = __builtin_amdgcn_alignbyte(Rw, Cw, 3);   // pixels at x + 3
-                const uint32_t P12 = __builtin_amdgcn_alignbyte(Cw, Lw, 1);  // pixels at x - 3
-                pm = 0;
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    // an arc of 9 equal-polarity ring pixels contains pixel 0 or 8 AND pixel 4 or 12 of that polarity
-                    const int v = (int)byte_of(Cw, k);
-                    const int d0 = v - (int)byte_of(Bw, k), d8 = v - (int)byte_of(Tw, k);
-                    const int d4 = v - (int)byte_of(P4, k), d12 = v - (int)byte_of(P12, k);
-                    const bool dark = ((d0 > thr) | (d8 > thr)) & ((d4 > thr) | (d12 > thr));
-                    const bool brig = ((d0 < -thr) | (d8 < -thr)) & ((d4 < -thr) | (d12 < -thr));
-                    pm |= (uint32_t)((dark | brig) && (4 * g + k < lim_x)) << k;
-                }
-            }
-            // wave-level compaction: one LDS atomic per wave and row group, positions from ballots
-            int base = 0;
+            const bool row_ok = sy < lim_y;
+            const uint32_t* rowp = s_pix + (sy + 3) * (FP_PITCH / 4) + g; // rows/columns exist in LDS for every lane
+            const uint32_t Lw = rowp[0], Cw = rowp[1], Rw = rowp[2];
+            const uint32_t Tw = rowp[1 - 3 * (FP_PITCH / 4)], Bw = rowp[1 + 3 * (FP_PITCH / 4)];
+            const uint32_t P4 = __builtin_amdgcn_alignbyte(Rw, Cw, 3);   // pixels at x + 3
+            const uint32_t P12 = __builtin_amdgcn_alignbyte(Cw, Lw, 1);  // pixels at x - 3
+            bool pass[4];
             unsigned long long bal[4];
             int tot = 0;
 #pragma unroll
-            for (int k = 0; k < 4; k++) { bal[k] = __ballot((pm >> k) & 1u); tot += __popcll(bal[k]); }
-            if (tot) {
-                if ((tid & 63) == 0) base = atomicAdd(&s_n1, tot);
+            for (int k = 0; k < 4; k++) {
+                const uint32_t v = byte_of(Cw, k);
+                const uint32_t hi = v + (uint32_t)thr;
+                const int lo = (int)v - thr;
+                const uint32_t p0 = byte_of(Bw, k), p8 = byte_of(Tw, k), p4 = byte_of(P4, k), p12 = byte_of(P12, k);
+                const bool brig = ((p0 > hi) | (p8 > hi)) & ((p4 > hi) | (p12 > hi));
+                const bool dark = (((int)p0 < lo) | ((int)p8 < lo)) & (((int)p4 < lo) | ((int)p12 < lo));
+                pass[k] = (brig | dark) & row_ok & (4 * g + k < lim_x);
+                bal[k] = __builtin_amdgcn_ballot_w64(pass[k]);
+                tot += __popcll(bal[k]);
+            }
+            if (tot) { // wave-uniform
+                int base = 0;
+                if (lane == 0) base = atomicAdd(&s_n1, tot);
                 base = __shfl(base, 0);
-                const unsigned long long below = (1ull << (tid & 63)) - 1ull;
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
-                    if ((pm >> k) & 1u) s_list[base + __popcll(bal[k] & below)] = (uint16_t)(sy * FS_W + 4 * g + k);
+                    if (pass[k]) s_list[base + __popcll(bal[k] & below)] = (uint16_t)(sy * FS_W + 4 * g + k);
                     base += __popcll(bal[k]);
                 }
             }
