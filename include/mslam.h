@@ -297,6 +297,11 @@ typedef struct {
 } mslam_ba_dev_view;
 int mslam_ba_plan_view(mslam_ba_plan* plan, mslam_ba_dev_view* view);
 int mslam_ba_plan_set_state(mslam_ba_plan* plan, const double* poses_host, const double* points_host);
+/* Edge weights and robust kernel of an existing plan (structure unchanged): info_host (n_edges, optional) replaces
+ * the per-edge information scale -- 0 takes an edge out of the optimisation, which is what g2o's setLevel(1) +
+ * initializeOptimization(0) does in Util::PoseBundleAdjustment's inlier/outlier rounds (src/Util.cpp:305-339);
+ * huber_delta <= 0 removes the robust kernel (setRobustKernel(NULL), :335). */
+int mslam_ba_plan_set_robust(mslam_ba_plan* plan, const double* info_host, double huber_delta);
 /* enqueue one linearisation on the context's stream (no sync) */
 int mslam_ba_plan_build_dev(mslam_ba_plan* plan);
 /* copy the built system to host buffers (syncs) */

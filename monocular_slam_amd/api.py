@@ -286,6 +286,11 @@ class BaPlan:
         self.ctx._check(lib().mslam_ba_plan_set_state(self._h, _p(a, f64p) if a is not None else None,
                                                       _p(b, f64p) if b is not None else None), "mslam_ba_plan_set_state")
 
+    def set_robust(self, info=None, huber_delta=0.0):
+        a = np.ascontiguousarray(info, np.float64) if info is not None else None
+        self.ctx._check(lib().mslam_ba_plan_set_robust(self._h, _p(a, f64p) if a is not None else None,
+                                                       C.c_double(huber_delta)), "mslam_ba_plan_set_robust")
+
     def build_dev(self):
         self.ctx._check(lib().mslam_ba_plan_build_dev(self._h), "mslam_ba_plan_build_dev")
 

@@ -573,6 +573,20 @@ int mslam_ba_plan_set_state(mslam_ba_plan* pl, const double* poses, const double
     return MSLAM_OK;
 }
 
+int mslam_ba_plan_set_robust(mslam_ba_plan* pl, const double* info, double huber_delta)
+{
+    if (!pl) return MSLAM_ERR_INVALID;
+    mslam_ctx* ctx = pl->ctx;
+    MSLAM_TRY(ctx_set_device(ctx));
+    if (info) {
+        HIP_TRY(ctx, hipMemcpyAsync(const_cast<double*>(pl->dev.info), info, sizeof(double) * pl->dev.n_edges, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    pl->dev.huber_delta = huber_delta;
+    pl->dev.dsqr = (float)(huber_delta * huber_delta);
+    return MSLAM_OK;
+}
+
 int mslam_ba_plan_build_dev(mslam_ba_plan* pl)
 {
     if (!pl) return MSLAM_ERR_INVALID;

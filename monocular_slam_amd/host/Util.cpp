@@ -112,17 +112,22 @@ void Util::LocalBundleAdjustment(DataManager& data, int first_free_frame_id, int
           (double)THRESH_HUBER_FULL_BA, true);
 }
 
-void Util::PoseBundleAdjustment(Frame& frame, DataManager& data, int /*n_round*/)
+bool Util::poseBARoundsEnabled = false;
+std::vector<uint8_t> Util::lastPoseBAOutliers;
+
+void Util::PoseBundleAdjustment(Frame& frame, DataManager& data, int n_round)
 {
-    // one round of POSE_BA_ITER iterations (the reference leaves its round loop after the first optimize, :312)
-    runBA(data, data.frames, data.mapPoints, POSE_BA_ITER, true, 0, &frame, (double)THRESH_HUBER, true);
+    // one round of POSE_BA_ITER iterations (the reference leaves its round loop after the first optimize, :312),
+    // or the full n_round loop of :305-339 when poseBARoundsEnabled
+    runBA(data, data.frames, data.mapPoints, POSE_BA_ITER, true, 0, &frame, (double)THRESH_HUBER, true,
+          poseBARoundsEnabled ? std::max(1, n_round) : 1);
 }
 
 // frames with frameID < first_free_frame_id are fixed (1 == the reference's "fix frame 0", src/Util.cpp:72).
 // only_pose_frame != nullptr: pose-only BA of that frame -- its pose is the single free vertex, every map point it
 // observes is a fixed parameter (EdgeSE3ProjectXYZOnlyPose): no point blocks, a 6x6 system per LM trial.
 void Util::runBA(DataManager& data, std::vector<Frame>& frames, std::vector<MapPoint>& map_points, int n_iterations, bool b_robust,
-                 int first_free_frame_id, Frame* only_pose_frame, double huber_delta, bool write_back)
+                 int first_free_frame_id, Frame* only_pose_frame, double huber_delta, bool write_back, int pose_rounds)
 {
     const bool poseOnly = only_pose_frame != nullptr;
     lastChi2History.clear();
@@ -212,6 +217,19 @@ void Util::runBA(DataManager& data, std::vector<Frame>& frames, std::vector<MapP
         MslamRuntime::check(mslam_ba_plan_download(plan, &v), "mslam_ba_plan_download");
         return v.robust_chi2;
     };
+    // ---- PoseBundleAdjustment's rounds (src/Util.cpp:305-339); every other entry point runs the loop body once
+    const int rounds = poseOnly ? std::max(1, pose_rounds) : 1;
+    const std::vector<double> poses0 = poses;
+    std::vector<double> info_cur = info;
+    std::vector<uint8_t> is_outlier((size_t)prob.n_edges, 1);             // "mark everyone as outlier first" (:296)
+    bool robust_on = b_robust;
+    for (int rd = 0; rd < rounds; rd++) {
+    if (rounds > 1) {
+        poses = poses0;                                                   // "reset pose every time" (:308)
+        MslamRuntime::check(mslam_ba_plan_set_robust(plan, info_cur.data(), robust_on ? huber_delta : 0.0), "mslam_ba_plan_set_robust");
+        lambda = -1; ni = 2; nBad = 0;
+        lastChi2History.clear();                                          // diagnostics of the last round
+    }
     for (int it = 0; it < n_iterations; it++) {
         linearise(true);
         double currentChi = s.robust_chi2, tempChi = currentChi;
@@ -286,6 +304,22 @@ void Util::runBA(DataManager& data, std::vector<Frame>& frames, std::vector<MapP
         if ((iniChi - currentChi) * 1e3 < iniChi) nBad++; else nBad = 0;
         if (nBad >= 3) break;
     }
+    if (rounds > 1 && rd != 0) {
+        // classify at the optimised pose: e->computeError(); (float)e->chi2() <= CHI2_THRESH (:316-333).  Only edges
+        // still marked outlier are looked at; an inlier stays an inlier.
+        linearise(true);
+        for (int j = 0; j < prob.n_edges; j++) {
+            if (is_outlier[(size_t)j]) {
+                const double ex = s.err[(size_t)2 * j], ey = s.err[(size_t)2 * j + 1];
+                const float chi2_error = (float)(info[(size_t)j] * (ex * ex + ey * ey));
+                if (chi2_error <= CHI2_THRESH) { is_outlier[(size_t)j] = 0; info_cur[(size_t)j] = info[(size_t)j]; }   // setLevel(0)
+                else { is_outlier[(size_t)j] = 1; info_cur[(size_t)j] = 0.0; }                                          // setLevel(1)
+            }
+        }
+        if (rd == rounds - 2) robust_on = false;                          // setRobustKernel(NULL) (:335)
+    }
+    } // rounds
+    if (poseOnly) lastPoseBAOutliers = is_outlier;
     mslam_ba_plan_destroy(plan);
 
     // ---- write back (src/Util.cpp:184-219)

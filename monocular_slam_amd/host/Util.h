@@ -16,6 +16,13 @@ public:
     // Single-pose refinement against fixed map points (src/Util.cpp:222-358: unary EdgeSE3ProjectXYZOnlyPose edges,
     // Huber delta = sqrt(5.991), POSE_BA_ITER iterations, effectively one round because of the `break` at :312).
     static void PoseBundleAdjustment(Frame& frame, DataManager& data, int n_round = 5);
+    // false (default): as the reference executes today.  true: the n_round inlier/outlier rounds that the `break` at
+    // src/Util.cpp:312 disables run as written (:305-339): every round restarts from the frame's pose and optimises the
+    // level-0 edges; from the second round on, edges still marked outlier are re-classified by chi2 <= CHI2_THRESH
+    // (outliers leave the optimisation), and after round n_round-2 the robust kernel is dropped.
+    static bool poseBARoundsEnabled;
+    // per edge of the last PoseBundleAdjustment call: 1 = classified outlier (all 1 if the rounds did not run)
+    static std::vector<uint8_t> lastPoseBAOutliers;
     static Frame* findFrameById(std::vector<Frame>& frames, int target_id);
     static MapPoint* findMapPointById(std::vector<MapPoint>& map_points, int target_id);
     // CSV fixtures in the reference's formats (src/Util.cpp:384-588) and the matching writers (the reference has none)
@@ -31,5 +38,5 @@ public:
     static std::vector<double> lastChi2History;
 private:
     static void runBA(DataManager& data, std::vector<Frame>& frames, std::vector<MapPoint>& map_points, int n_iterations, bool b_robust,
-                      int first_free_frame_id, Frame* only_pose_frame, double huber_delta, bool write_back);
+                      int first_free_frame_id, Frame* only_pose_frame, double huber_delta, bool write_back, int pose_rounds = 1);
 };

@@ -58,7 +58,9 @@ def _run(tmp, *flags):
     out = subprocess.run([DEMO, str(tmp / "Frames.csv"), str(tmp / "MapPoints.csv"), *[repr(float(v)) for v in (K[0, 0], K[1, 1], K[0, 2], K[1, 2])],
                           str(tmp / "FramesOptimised.csv"), str(tmp / "MapPointsOptimised.csv"), *flags], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr
-    chi = np.array(out.stdout.strip().split()[1:], float)
+    lines = out.stdout.strip().splitlines()
+    chi = np.array(lines[0].split()[1:], float)
+    _run.outliers = np.array(lines[1].split()[1:], int) if len(lines) > 1 else None
     fr = np.loadtxt(tmp / "FramesOptimised.csv", delimiter=",", ndmin=2)
     mp = np.loadtxt(tmp / "MapPointsOptimised.csv", delimiter=",", ndmin=2)
     Rts = np.stack([np.c_[r[1:10].reshape(3, 3), r[10:13]] for r in fr])
@@ -137,3 +139,45 @@ def test_pose_only_ba(tmp_path, oracle):
     assert (np.diff(chi) <= 0).all()
     for j in (0, 1, 3):
         np.testing.assert_allclose(Rts[j], _Rt_of_pose7(oracle, pr["poses"][j]), rtol=0, atol=1e-12)
+
+
+def test_pose_ba_rounds_reenabled(tmp_path, oracle):
+    """f4: the inlier/outlier rounds of Util::PoseBundleAdjustment (src/Util.cpp:305-339) as written, minus the `break`:
+    restart from the frame's pose each round, from round 1 on classify still-outlier edges by (float)chi2 <= 5.991 at
+    the optimised pose (outliers leave the optimisation), drop the robust kernel after round n-2."""
+    n_round = 5
+    pr, feats, observers = _scenario(4, 200, 9)
+    pr["points"] = pr["points_gt"].copy()
+    rng = np.random.default_rng(4)
+    for k in rng.choice(len(feats[2]), 25, replace=False):            # gross mismatches on the frame being refined
+        x, y, s_, i = feats[2][k]
+        feats[2][k] = (x + rng.uniform(15, 40), y - rng.uniform(15, 40), s_, i)
+    _write_csv(tmp_path, pr, feats, observers)
+    chi, Rts, pts = _run(tmp_path, "--pose", "2", "--pose-rounds", str(n_round))
+    flagged = _run.outliers
+    q = _oracle_graph(pr, feats, observers)
+    keep = q["edge_pose"] == 2
+    for k in ("edge_pose", "edge_point", "obs", "info"):
+        q[k] = np.ascontiguousarray(q[k][keep])
+    q["n_edges"] = int(keep.sum())
+    q["edge_pose"] = np.zeros(q["n_edges"], np.int32)
+    q["poses"] = pr["poses"][2:3].copy(); q["intr"] = pr["intr"][2:3].copy(); q["pose_fixed"] = np.zeros(1, np.uint8); q["n_poses"] = 1
+    delta = float(np.float32(np.sqrt(5.991)))
+    info0 = q["info"].copy()
+    info_cur, outl, robust = info0.copy(), np.ones(q["n_edges"], bool), True
+    for rd in range(n_round):
+        qq = dict(q); qq["info"] = info_cur.copy(); qq["huber_delta"] = delta if robust else 0.0
+        r = oracle.ba_optimize(qq, 10, points_fixed=True)
+        if rd != 0:
+            qe = dict(qq); qe["poses"] = r["poses"].copy()
+            e = oracle.ba_build(qe)["err"]
+            c = (info0 * (e[:, 0] ** 2 + e[:, 1] ** 2)).astype(np.float32)
+            newly_in = outl & (c <= np.float32(5.991))
+            outl = outl & ~newly_in
+            info_cur = np.where(outl, 0.0, info0)
+            if rd == n_round - 2:
+                robust = False
+    np.testing.assert_allclose(chi, r["chi2"], rtol=1e-8)
+    np.testing.assert_allclose(Rts[2], _Rt_of_pose7(oracle, r["poses"][0]), rtol=1e-6, atol=1e-8)
+    np.testing.assert_array_equal(flagged.astype(bool), outl)
+    assert 20 <= outl.sum() <= 60          # the planted mismatches (+ the scenario's own gross errors) were thrown out
