@@ -73,6 +73,16 @@ struct OrbDev {
     int32_t* frame_status; // [B]
 };
 
+// XCD-aware work-item order: the dispatcher deals consecutive workgroups round-robin over the 8 XCDs (each with its own
+// L2), so workgroups orig, orig + 8, ... share an L2.  This bijection gives every XCD one CONTIGUOUS range of the
+// logical tile order, so tiles that share image rows / cache lines (tile halos, neighbouring keypoint patches) are
+// fetched into one L2 instead of up to eight.  Speed only: any placement computes the same result.
+__device__ __forceinline__ unsigned xcd_contiguous(unsigned orig, unsigned nwg)
+{
+    const unsigned q = nwg >> 3, r = nwg & 7u, xcd = orig & 7u;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+}
+
 // ---------------------------------------------------------------- K1: gray + pyramid
 __global__ void bgr2gray_k(const uint8_t* __restrict__ src, int w, int h, int stride, long long fstride, int ch,
                            uint8_t* __restrict__ dst, int dpitch, long long dfstride)
@@ -95,7 +105,7 @@ void resize_k(const uint8_t* __restrict__ src, int spitch, long long sfstride,
               const int2* __restrict__ xtab, const int4* __restrict__ ytab)
 {
     __shared__ uint32_t s_src[RS_LDS_DW];
-    const int tid = threadIdx.x, b = blockIdx.z;
+    const int tid = threadIdx.x, b = blockIdx.z; // (an XCD-contiguous order was measured slower here: +11 %)
     const int x0 = blockIdx.x * RS_TW, y0 = blockIdx.y * RS_TH;
     const int xl = min(x0 + RS_TW, dw) - 1, yl = min(y0 + RS_TH, dh) - 1;
     // source footprint of the tile (tables are monotone)
@@ -199,8 +209,9 @@ void fast_nms_k(OrbDev od)
     static_assert(((FT_W + 1) / 2) * ((FT_H + 1) / 2) * 4 <= FP_H * FP_PITCH, "emit buffer must fit in the pixel tile");
 
     // tile -> (frame, level, tx, ty): blocks of one frame are consecutive
-    const int b = blockIdx.x / od.tiles_per_frame;
-    int t = blockIdx.x % od.tiles_per_frame;
+    const unsigned wg = xcd_contiguous(blockIdx.x, gridDim.x);
+    const int b = (int)(wg / (unsigned)od.tiles_per_frame);
+    int t = (int)(wg % (unsigned)od.tiles_per_frame);
     int l = 0;
     while (l + 1 < od.L && t >= od.lv[l + 1].tile_base) l++;
     const LevelDesc& lv = od.lv[l];
@@ -522,8 +533,9 @@ void describe_k(OrbDev od, DescArgs out)
     __shared__ uint32_t s_h[DESC_WAVES][4 * DH_CG * HT_DW];
     __shared__ uint32_t s_blur[DESC_WAVES][DB_N * BT_DW];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int b = blockIdx.y;
-    const int g = blockIdx.x * DESC_WAVES + wave; // keypoint index inside the frame
+    const unsigned wg = xcd_contiguous(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y);
+    const int b = (int)(wg / gridDim.x), bx = (int)(wg % gridDim.x);
+    const int g = bx * DESC_WAVES + wave; // keypoint index inside the frame
     // level offsets (<= 16 counts)
     int total = 0, l = -1, off = 0;
     for (int i = 0; i < od.L; i++) {
@@ -539,7 +551,7 @@ void describe_k(OrbDev od, DescArgs out)
     }
     // blocks entirely beyond the keypoint count have nothing to do (the grid is sized for the capacity); the condition is
     // uniform over the block, so no barrier is skipped by part of it
-    if (blockIdx.x > 0 && (bad || blockIdx.x * DESC_WAVES >= total)) return;
+    if (bx > 0 && (bad || bx * DESC_WAVES >= total)) return;
     const bool active = !bad && l >= 0; // wave-uniform; inactive waves of a partial block still reach the barriers
     if (l < 0) l = 0;
     const LevelDesc& lv = od.lv[l];
