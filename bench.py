@@ -192,6 +192,22 @@ def main():
                 kern[k] = (kern.get(k, (0.0, 0))[0] + ms, kern.get(k, (0.0, 0))[1] + n)
             c.profile_enable(0)
 
+    # third pass: the same launches one phase at a time (nothing else on the chip) -> exclusive kernel durations, reported
+    # beside the concurrent ones; the headline value never uses them
+    kern_x = {}
+    if not args.no_kernel_events:
+        for c in ctxs:
+            c.profile_enable(64 * 3)
+        for _ in range(3):
+            for tb in tbs:
+                tb.extract(); tb.match_prev(); tb.sync()
+                tb.pnp_ransac(); tb.sync()
+                tb.cur = 1 - tb.cur
+        for c in ctxs:
+            for k, (ms, n) in c.profile_read().items():
+                kern_x[k] = (kern_x.get(k, (0.0, 0))[0] + ms, kern_x.get(k, (0.0, 0))[1] + n)
+            c.profile_enable(0)
+
     if rank == 0:
         frames_total = world * B * args.steps
         value = frames_total / elapsed
@@ -214,11 +230,12 @@ def main():
             unit = KERNEL_UNIT.get(dom, "extract")
             launches_per_step = kern[dom][1] / args.steps
             pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-            def roof(kname):
+            def roof(kname, dur_ms=None):
                 u = KERNEL_UNIT.get(kname, "extract")
                 lps = kern[kname][1] / args.steps
                 alg_k = ALG_BYTES[u] * B / lps
-                ach = alg_k / (per[kname] * 1e-3) / 1e9
+                dur_ms = per[kname] if dur_ms is None else dur_ms
+                ach = alg_k / (dur_ms * 1e-3) / 1e9
                 tr = None
                 if os.path.exists(pmc_path):
                     try:  # PMC passes were collected at 32 frames per launch: only comparable per launch at that size
@@ -228,7 +245,7 @@ def main():
                     except Exception:
                         tr = None
                 return {"bound": "hbm", "kernel": kname, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                        "traffic": tr, "algorithmic_bytes_per_launch": alg_k, "avg_launch_ms": per[kname], "unit_priced": u}
+                        "traffic": tr, "algorithmic_bytes_per_launch": alg_k, "avg_launch_ms": dur_ms, "unit_priced": u}
 
             out["roofline"] = roof(dom)
             out["roofline"]["note"] = ("algorithmic bytes (SURVEY 8d) of the %s unit x %d frames per launch; launch duration measured with HIP "
@@ -236,6 +253,10 @@ def main():
                                        "(DESIGN.md section 4)" % (out["roofline"]["unit_priced"], SB, len(ctxs) - 1))
             out["roofline_top_kernels"] = [roof(k) for k in sorted(tot, key=tot.get, reverse=True)[:4]]
             out["kernel_ms_per_step"] = {k: v[0] / args.steps for k, v in sorted(kern.items(), key=lambda kv: -kv[1][0])}
+            if kern_x:  # same kernels alone on the chip (one phase at a time, not part of the timed value)
+                per_x = {k: v[0] / max(1, v[1]) for k, v in kern_x.items()}
+                out["roofline_exclusive"] = [roof(k, per_x[k]) for k in sorted(tot, key=tot.get, reverse=True)[:4] if k in per_x]
+                out["kernel_ms_per_launch_exclusive"] = {k: round(v, 5) for k, v in sorted(per_x.items(), key=lambda kv: -kv[1])}
         if args.cpu_frames > 0 and world == 1:
             out["cpu_baseline"] = cpu_baseline(frames, pnp, args.cpu_frames)
         print(json.dumps(out))

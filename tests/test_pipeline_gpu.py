@@ -90,3 +90,47 @@ def test_optimiser_stage_reduces_robust_chi2(tmp_path, sequence):
     assert chi is not None and len(chi) >= 2 and (np.diff(chi) <= 1e-9 * chi[0]).all()
     np.testing.assert_allclose(poses[0], np.eye(3, 4), atol=1e-12)
     assert _rot_angle(poses[2][:, :3], gt[2][0]) < 1.0
+
+
+def test_frame_loader_sequence_matches_raw_pipeline(tmp_path, sequence):
+    """f2: FrameLoader (TUM-style tree: rgb/<timestamp>.png, groundtruth.txt) -> ProcessingPipeline gives what the raw-frame
+    demo gives on the same pixels and intrinsics; ground truth is attached to the frames as the reference does."""
+    from test_frameloader_cpu import write_png
+    frames, gt = sequence
+    root = tmp_path / "synthetic_f1_sequence"
+    (root / "rgb").mkdir(parents=True)
+    stamps = [1305031102.175304 + 0.0333 * i for i in range(len(frames))]
+    for i in np.random.default_rng(0).permutation(len(frames)):          # directory order must not matter
+        write_png(root / "rgb" / f"{stamps[i]:.6f}.png", frames[i].astype(np.uint16))
+    recs = []
+    rng = np.random.default_rng(3)
+    for i, ts in enumerate(stamps):
+        q = rng.normal(size=4); q /= np.linalg.norm(q)
+        recs.append((ts - 0.004, *rng.uniform(-1, 1, 3), *q))
+    with open(root / "groundtruth.txt", "w") as f:
+        f.write("# ground truth trajectory\n# file: synthetic\n# timestamp tx ty tz qx qy qz qw\n")
+        for r in recs:
+            f.write(" ".join(f"{v:.9f}" if k else f"{v:.6f}" for k, v in enumerate(r)) + "\n")
+    out = tmp_path / "seq_out.txt"
+    demo = os.path.join(ROOT, "monocular_slam_amd", "host", "mslam_sequence_demo")
+    r = subprocess.run([demo, str(root), "0", "100", "1", str(out), "--no-dist", "--pnp-hyps", "256", "--pnp-thr", "3.0"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    poses, gts = [], []
+    for line in open(out):
+        tok = line.split()
+        if tok[0] == "frame":
+            poses.append(np.array(tok[3:], float).reshape(3, 4))
+        elif tok[0] == "gt":
+            gts.append(np.array(tok[2:], float).reshape(3, 4))
+    K = np.array([[517.3, 0, 318.6], [0, 516.5, 255.3], [0, 0, 1.0]])   # loadCameraIntrinsics_kinect
+    ref, _, _, _ = _run_demo(tmp_path, frames, K, "--no-dist", "--pnp-hyps", "256", "--pnp-thr", "3.0")
+    assert len(poses) == len(frames) == len(gts)
+    for a, b in zip(poses, ref):
+        np.testing.assert_array_equal(a, b)
+    for g, rec in zip(gts, recs):
+        tx, ty, tz, qx, qy, qz, qw = [float(f"{v:.9f}") for v in rec[1:]]
+        R = np.array([[1 - 2 * qy * qy - 2 * qz * qz, 2 * qx * qy - 2 * qz * qw, 2 * qx * qz + 2 * qy * qw],
+                      [2 * qx * qy + 2 * qz * qw, 1 - 2 * qx * qx - 2 * qz * qz, 2 * qy * qz - 2 * qx * qw],
+                      [2 * qx * qz - 2 * qy * qw, 2 * qy * qz + 2 * qx * qw, 1 - 2 * qx * qx - 2 * qy * qy]])
+        np.testing.assert_allclose(g, np.c_[R, -R @ np.array([tx, ty, tz])], rtol=1e-12, atol=1e-12)  # R kept, t' = -R t (as written)
