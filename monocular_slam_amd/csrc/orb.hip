@@ -98,13 +98,17 @@ __global__ void bgr2gray_k(const uint8_t* __restrict__ src, int w, int h, int st
 // LDS with coalesced aligned dword loads (byte gathers from global memory are VMEM-issue bound: ~22 CU-cycles per
 // wave-instruction), then each lane computes 4 px x 2 rows from LDS bytes and writes packed 32-bit words.
 // Column table entry {sx0 | sx1 << 16, a0 | a1 << 16}; row table entry {sy0, sy1, b0, b1} (wave-uniform).
-constexpr int RS_TW = 256, RS_TH = 8, RS_LDS_DW = 4096;
+// Separable evaluation inside the tile (same integer operations as OpenCV's two passes): the horizontal sums
+// S = src[sx0] a0 + src[sx1] a1 are formed ONCE per source row of the tile's footprint (about 1.2 + 1/8 rows per output
+// row at the pyramid's scale instead of 2) and kept as S >> 4 (u16) in LDS; the vertical pass then reads two of them.
+constexpr int RS_TW = 256, RS_TH = 8, RS_LDS_DW = 1536, RS_HROWS = 16; // 6 + 8 KiB of LDS: 8 workgroups per CU
 __global__ __launch_bounds__(256)
 void resize_k(const uint8_t* __restrict__ src, int spitch, long long sfstride,
               uint8_t* __restrict__ dst, int dw, int dh, int dpitch, long long dfstride,
               const int2* __restrict__ xtab, const int4* __restrict__ ytab)
 {
     __shared__ uint32_t s_src[RS_LDS_DW];
+    __shared__ uint32_t s_h[RS_HROWS * RS_TW / 2];
     const int tid = threadIdx.x, b = blockIdx.z; // (an XCD-contiguous order was measured slower here: +11 %)
     const int x0 = blockIdx.x * RS_TW, y0 = blockIdx.y * RS_TH;
     const int xl = min(x0 + RS_TW, dw) - 1, yl = min(y0 + RS_TH, dh) - 1;
@@ -113,18 +117,72 @@ void resize_k(const uint8_t* __restrict__ src, int spitch, long long sfstride,
     const int sy_lo = ytab[y0].x, sy_hi = ytab[yl].y;
     const int sxa = sx_lo & ~3;
     const int ndw = ((sx_hi - sxa) >> 2) + 1, nrows = sy_hi - sy_lo + 1;
-    const bool use_lds = ndw * nrows <= RS_LDS_DW; // always true for pyramid scales <= ~3
+    const bool use_lds = ndw * nrows < RS_LDS_DW && nrows <= RS_HROWS; // true for pyramid scales up to ~1.6
     const uint8_t* sb = src + b * sfstride;
-    if (use_lds) {
-        const int max_dw = spitch / 4 - 1;
-        for (int i = tid; i < ndw * nrows; i += 256) {
-            const int r = i / ndw, c = i - r * ndw;
-            s_src[i] = reinterpret_cast<const uint32_t*>(sb + (size_t)(sy_lo + r) * spitch)[min(sxa / 4 + c, max_dw)];
-        }
-    }
-    __syncthreads();
     const int tx = tid & 63, ty = tid >> 6;
     const int x4 = x0 + tx * 4;
+    uint8_t* db = dst + b * dfstride;
+    if (use_lds) {
+        {   // stage the footprint; all loads of a lane are issued before the first LDS store (one memory latency, not one per pass)
+            const int max_dw = spitch / 4 - 1, spitch_dw = spitch / 4;
+            const uint32_t* sb32 = reinterpret_cast<const uint32_t*>(sb);
+            const int n = ndw * nrows; // < RS_LDS_DW = 6 * 256
+            uint32_t v[RS_LDS_DW / 256];
+            // (row, column) of element tid + 256 k without a division per element: one division, then steps of 256
+            const int qs = 256 / ndw, ms = 256 - qs * ndw; // wave-uniform
+            int r = tid / ndw, c = tid - r * ndw;
+#pragma unroll
+            for (int k = 0; k < RS_LDS_DW / 256; k++) {
+                const int i = tid + 256 * k;
+                v[k] = i < n ? sb32[(sy_lo + r) * spitch_dw + min(sxa / 4 + c, max_dw)] : 0u;
+                c += ms; r += qs;
+                if (c >= ndw) { c -= ndw; r++; }
+            }
+#pragma unroll
+            for (int k = 0; k < RS_LDS_DW / 256; k++) {
+                const int i = tid + 256 * k;
+                if (i < n) s_src[i] = v[k];
+            }
+        }
+        __syncthreads();
+        int o0[4], a0[4], a1[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int2 t = xtab[min(x4 + i, dw - 1)];
+            // sx1 == sx0 + 1 except at the clamped right border, where a1 == 0 (fx = 0): reading sx0 + 1 is then harmless
+            o0[i] = (t.x & 0xFFFF) - sxa; a0[i] = t.y & 0xFFFF; a1[i] = (int)((unsigned)t.y >> 16);
+        }
+        const uint8_t* lds = reinterpret_cast<const uint8_t*>(s_src);
+        const int lpitch = ndw * 4;
+        for (int r = ty; r < nrows; r += 4) { // wave-uniform row
+            const uint8_t* row = lds + r * lpitch;
+            uint32_t h[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) h[i] = (uint32_t)(row[o0[i]] * a0[i] + row[o0[i] + 1] * a1[i]) >> 4; // <= 32640
+            *reinterpret_cast<uint2*>(&s_h[(r * RS_TW + tx * 4) / 2]) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+        }
+        __syncthreads();
+        if (x4 >= dw) return;
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+            const int y = y0 + ty * 2 + r;
+            if (y >= dh) break;
+            const int4 yt = ytab[y]; // {sy0, sy1, b0, b1}
+            const uint2 ha = *reinterpret_cast<const uint2*>(&s_h[((yt.x - sy_lo) * RS_TW + tx * 4) / 2]);
+            const uint2 hb = *reinterpret_cast<const uint2*>(&s_h[((yt.y - sy_lo) * RS_TW + tx * 4) / 2]);
+            const uint32_t h0[4] = { ha.x & 0xFFFFu, ha.x >> 16, ha.y & 0xFFFFu, ha.y >> 16 };
+            const uint32_t h1[4] = { hb.x & 0xFFFFu, hb.x >> 16, hb.y & 0xFFFFu, hb.y >> 16 };
+            uint32_t out = 0;
+#pragma unroll
+            for (int i = 0; i < 4; i++) { // v <= 255: no masking needed
+                const uint32_t v = ((((uint32_t)yt.z * h0[i]) >> 16) + (((uint32_t)yt.w * h1[i]) >> 16) + 2u) >> 2;
+                out |= v << (8 * i);
+            }
+            *reinterpret_cast<uint32_t*>(db + (size_t)y * dpitch + x4) = out;
+        }
+        return;
+    }
+    // generic path (footprint larger than the LDS tiles): straight from global memory
     if (x4 >= dw) return;
     int sx0[4], sx1[4], a0[4], a1[4];
 #pragma unroll
@@ -132,35 +190,20 @@ void resize_k(const uint8_t* __restrict__ src, int spitch, long long sfstride,
         const int2 t = xtab[min(x4 + i, dw - 1)];
         sx0[i] = t.x & 0xFFFF; sx1[i] = (int)((unsigned)t.x >> 16); a0[i] = t.y & 0xFFFF; a1[i] = (int)((unsigned)t.y >> 16);
     }
-    uint8_t* db = dst + b * dfstride;
-    const uint8_t* lds = reinterpret_cast<const uint8_t*>(s_src);
-    const int lpitch = ndw * 4;
 #pragma unroll
     for (int r = 0; r < 2; r++) {
         const int y = y0 + ty * 2 + r;
         if (y >= dh) break;
-        const int4 yt = ytab[y]; // {sy0, sy1, b0, b1}
+        const int4 yt = ytab[y];
         uint32_t out = 0;
-        if (use_lds) {
-            const uint8_t* r0 = lds + (yt.x - sy_lo) * lpitch - sxa;
-            const uint8_t* r1 = lds + (yt.y - sy_lo) * lpitch - sxa;
+        const uint8_t* r0 = sb + (size_t)yt.x * spitch;
+        const uint8_t* r1 = sb + (size_t)yt.y * spitch;
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const int S0 = r0[sx0[i]] * a0[i] + r0[sx1[i]] * a1[i];
-                const int S1 = r1[sx0[i]] * a0[i] + r1[sx1[i]] * a1[i];
-                const int v = (((yt.z * (S0 >> 4)) >> 16) + ((yt.w * (S1 >> 4)) >> 16) + 2) >> 2;
-                out |= (uint32_t)(v & 255) << (8 * i);
-            }
-        } else {
-            const uint8_t* r0 = sb + (size_t)yt.x * spitch;
-            const uint8_t* r1 = sb + (size_t)yt.y * spitch;
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const int S0 = r0[sx0[i]] * a0[i] + r0[sx1[i]] * a1[i];
-                const int S1 = r1[sx0[i]] * a0[i] + r1[sx1[i]] * a1[i];
-                const int v = (((yt.z * (S0 >> 4)) >> 16) + ((yt.w * (S1 >> 4)) >> 16) + 2) >> 2;
-                out |= (uint32_t)(v & 255) << (8 * i);
-            }
+        for (int i = 0; i < 4; i++) {
+            const int S0 = r0[sx0[i]] * a0[i] + r0[sx1[i]] * a1[i];
+            const int S1 = r1[sx0[i]] * a0[i] + r1[sx1[i]] * a1[i];
+            const int v = (((yt.z * (S0 >> 4)) >> 16) + ((yt.w * (S1 >> 4)) >> 16) + 2) >> 2;
+            out |= (uint32_t)(v & 255) << (8 * i);
         }
         *reinterpret_cast<uint32_t*>(db + (size_t)y * dpitch + x4) = out;
     }
