@@ -238,6 +238,38 @@ __device__ __forceinline__ int fast_exact_score(const int* d)
     return max(amax, -bmin) - 1;
 }
 
+// The same on packed 16-bit pairs D[k] = (d[k], d[k + 8]), k = 0..7 (|d| <= 255): v_pk_min/max_i16 work on two ring positions
+// per instruction and the "+8" partner of a pair is a half swap, which the VOP3P op_sel modifiers provide for free.
+typedef short s2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ s2v swp(s2v a) { return __builtin_shufflevector(a, a, 1, 0); }
+__device__ __forceinline__ int fast_exact_score_pk(const s2v* D)
+{
+    s2v M2[8], N2[8], M4[8], N4[8], M8[8], N8[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const s2v nx = k + 1 < 8 ? D[k + 1] : swp(D[0]);
+        M2[k] = __builtin_elementwise_min(D[k], nx); N2[k] = __builtin_elementwise_max(D[k], nx);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const s2v mx = k + 2 < 8 ? M2[k + 2] : swp(M2[k + 2 - 8]), nx = k + 2 < 8 ? N2[k + 2] : swp(N2[k + 2 - 8]);
+        M4[k] = __builtin_elementwise_min(M2[k], mx); N4[k] = __builtin_elementwise_max(N2[k], nx);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const s2v mx = k + 4 < 8 ? M4[k + 4] : swp(M4[k - 4]), nx = k + 4 < 8 ? N4[k + 4] : swp(N4[k - 4]);
+        M8[k] = __builtin_elementwise_min(M4[k], mx); N8[k] = __builtin_elementwise_max(N4[k], nx);
+    }
+    s2v A = __builtin_elementwise_min(M8[0], swp(D[0])), Bv = __builtin_elementwise_max(N8[0], swp(D[0]));
+#pragma unroll
+    for (int k = 1; k < 8; k++) {
+        A = __builtin_elementwise_max(A, __builtin_elementwise_min(M8[k], swp(D[k])));
+        Bv = __builtin_elementwise_min(Bv, __builtin_elementwise_max(N8[k], swp(D[k])));
+    }
+    const int amax = max((int)A.x, (int)A.y), bmin = min((int)Bv.x, (int)Bv.y);
+    return max(amax, -bmin) - 1;
+}
+
 __device__ __forceinline__ uint32_t byte_of(uint32_t w, int k) { return (w >> (8 * k)) & 255u; }
 
 __global__ __launch_bounds__(FAST_THREADS)
@@ -349,19 +381,19 @@ void fast_nms_k(OrbDev od)
         const int i = s_list[j];
         const int sy = i / FS_W, sx = i % FS_W;
         const uint8_t* p = pix + (sy + 3) * FP_PITCH + (sx + 4);
-        const int v = p[0];
-        int d[16];
-        uint32_t mb = 0, md = 0; // ring brighter than v+thr / darker than v-thr
+        const uint32_t v = p[0];
+        // packed differences D[k] = (v - p[k], v - p[k + 8]).  The segment test needs no masks of its own: an arc of 9 ring
+        // pixels all darker than v - thr exists iff max over arcs of min(d) > thr, all brighter iff min over arcs of
+        // max(d) < -thr -- the two quantities the exact score is made of.  So: score + 1 > thr <=> corner.
+        const s2v V2 = __builtin_bit_cast(s2v, v | (v << 16));
+        s2v D[8];
 #pragma unroll
-        for (int k = 0; k < 16; k++) {
-            d[k] = v - p[ring_ofs(k)];
-            mb |= (uint32_t)(d[k] < -thr) << k;
-            md |= (uint32_t)(d[k] > thr) << k;
+        for (int k = 0; k < 8; k++) {
+            const uint32_t pk = (uint32_t)p[ring_ofs(k)] | ((uint32_t)p[ring_ofs(k + 8)] << 16);
+            D[k] = V2 - __builtin_bit_cast(s2v, pk);
         }
-        mb |= mb << 16; md |= md << 16;
-        uint32_t rb = mb & (mb >> 1); rb &= rb >> 2; rb &= rb >> 4; rb &= mb >> 8; // 9 contiguous
-        uint32_t rd = md & (md >> 1); rd &= rd >> 2; rd &= rd >> 4; rd &= md >> 8;
-        if (((rb | rd) & 0xFFFFu) != 0) s_score[i] = (uint8_t)fast_exact_score(d);
+        const int sc = fast_exact_score_pk(D);
+        if (sc >= thr) s_score[i] = (uint8_t)sc;
     }
     __syncthreads();
     if (od.ablate == 3) return;
