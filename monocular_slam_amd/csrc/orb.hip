@@ -30,6 +30,7 @@
 // All integer/float arithmetic is the plain-IEEE evaluation documented in DESIGN.md (built
 // with -ffp-contract=off); cvRound = round-half-even (__float2int_rn / rint).
 #include "common.h"
+#include "sincos_pio4.h"
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -711,7 +712,11 @@ void describe_k(OrbDev od, DescArgs out)
     // ---- 256 rotated binary tests; test t = j*64 + lane, ballot j = descriptor bytes 8j..8j+7
     float ang = angle;
     ang *= (float)(3.1415926535897932384626433832795 / 180.f);
-    const float ca = (float)cos((double)ang), sb = (float)sin((double)ang);
+    // (float)cos((double)ang), (float)sin((double)ang): quadrant-reduced kernels instead of the library calls (5x fewer
+    // f64 instructions); equal to libm after the float cast for every float in [0, 2 pi] (tests/trig_check.c, exhaustive)
+    double sd, cd;
+    mslam_sincos_2pi((double)ang, &sd, &cd);
+    const float ca = (float)cd, sb = (float)sd;
     const uint8_t* centre = reinterpret_cast<const uint8_t*>(blurT) + 18 * (BT_DW * 4) + 18; // [x][y]
     unsigned long long bits[4];
 #pragma unroll

@@ -412,3 +412,16 @@ def test_oracle_reproduces_golden_fixtures(oracle):
     for k in ("err", "chi2", "rho1", "Hpp", "Hll", "Hpl_val", "b"):
         np.testing.assert_allclose(s[k], g[k], rtol=1e-12, atol=1e-12 * np.abs(g[k]).max())
     np.testing.assert_array_equal(s["Hpl_col"], g["Hpl_col"])
+
+
+def test_descriptor_trig_kernel_equals_libm_after_float_cast(tmp_path):
+    """The GPU's quadrant-reduced sin/cos (csrc/sincos_pio4.h, plain C) vs libm, compared as the descriptor uses them:
+    (float)f((double)a) for float a in [0, 2 pi].  Every 5th float here (4 s); `trig_check 1` is the exhaustive run
+    (1 086 918 620 values, 0 differences, 14 s)."""
+    import subprocess
+    exe = tmp_path / "trig_check"
+    src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "trig_check.c")
+    subprocess.run(["gcc", "-O2", "-std=gnu11", "-ffp-contract=off", "-o", str(exe), src, "-lm"], check=True)
+    r = subprocess.run([str(exe), "5"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout
+    assert "differences 0" in r.stdout
