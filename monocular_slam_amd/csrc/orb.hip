@@ -337,16 +337,18 @@ void fast_nms_k(OrbDev od)
     const unsigned long long below = (1ull << lane) - 1ull;
     {
         const int g = tid & 31, ry = tid >> 5;
+        unsigned long long colok[4]; // lanes whose pixel 4g + k lies inside the needed score columns
+#pragma unroll
+        for (int k = 0; k < 4; k++) colok[k] = __builtin_amdgcn_ballot_w64(4 * g + k < lim_x);
 #pragma unroll
         for (int m = 0; m < FS_H / 8; m++) {
             const int sy = ry + 8 * m;
-            const bool row_ok = sy < lim_y;
+            const unsigned long long rowok = __builtin_amdgcn_ballot_w64(sy < lim_y);
             const uint32_t* rowp = s_pix + (sy + 3) * (FP_PITCH / 4) + g; // rows/columns exist in LDS for every lane
             const uint32_t Lw = rowp[0], Cw = rowp[1], Rw = rowp[2];
             const uint32_t Tw = rowp[1 - 3 * (FP_PITCH / 4)], Bw = rowp[1 + 3 * (FP_PITCH / 4)];
             const uint32_t P4 = __builtin_amdgcn_alignbyte(Rw, Cw, 3);   // pixels at x + 3
             const uint32_t P12 = __builtin_amdgcn_alignbyte(Cw, Lw, 1);  // pixels at x - 3
-            bool pass[4];
             unsigned long long bal[4];
             int tot = 0;
 #pragma unroll
@@ -355,10 +357,10 @@ void fast_nms_k(OrbDev od)
                 const uint32_t hi = v + (uint32_t)thr;
                 const int lo = (int)v - thr;
                 const uint32_t p0 = byte_of(Bw, k), p8 = byte_of(Tw, k), p4 = byte_of(P4, k), p12 = byte_of(P12, k);
-                const bool brig = ((p0 > hi) | (p8 > hi)) & ((p4 > hi) | (p12 > hi));
-                const bool dark = (((int)p0 < lo) | ((int)p8 < lo)) & (((int)p4 < lo) | ((int)p12 < lo));
-                pass[k] = (brig | dark) & row_ok & (4 * g + k < lim_x);
-                bal[k] = __builtin_amdgcn_ballot_w64(pass[k]);
+                // (p0 > hi | p8 > hi) & (p4 > hi | p12 > hi)  ==  min(max(p0, p8), max(p4, p12)) > hi, and mirrored
+                const unsigned long long brig = __builtin_amdgcn_ballot_w64(min(max(p0, p8), max(p4, p12)) > hi);
+                const unsigned long long dark = __builtin_amdgcn_ballot_w64(max(min((int)p0, (int)p8), min((int)p4, (int)p12)) < lo);
+                bal[k] = (brig | dark) & rowok & colok[k];
                 tot += __popcll(bal[k]);
             }
             if (tot) { // wave-uniform
@@ -367,7 +369,7 @@ void fast_nms_k(OrbDev od)
                 base = __shfl(base, 0);
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
-                    if (pass[k]) s_list[base + __popcll(bal[k] & below)] = (uint16_t)(sy * FS_W + 4 * g + k);
+                    if (__builtin_amdgcn_inverse_ballot_w64(bal[k])) s_list[base + __popcll(bal[k] & below)] = (uint16_t)(sy * FS_W + 4 * g + k);
                     base += __popcll(bal[k]);
                 }
             }
