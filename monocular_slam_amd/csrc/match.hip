@@ -25,9 +25,11 @@ constexpr uint32_t KEY_NONE = 0xFFFFFFFFu;
 
 __device__ __forceinline__ void top2_update(uint32_t& best, uint32_t& second, uint32_t k)
 {
-    // second = min(second, max(best, k)); best = min(best, k)
-    uint32_t hi = best > k ? best : k;
-    second = second < hi ? second : hi;
+    // invariant best <= second: the new second is the median of (best, second, k), the new best the minimum.
+    // Written in the min/max form the compiler folds into one v_med3_u32.
+    const uint32_t mn = best < second ? best : second, mx = best < second ? second : best;
+    const uint32_t t = mn > k ? mn : k;
+    second = mx < t ? mx : t;
     best = best < k ? best : k;
 }
 

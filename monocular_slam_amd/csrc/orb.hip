@@ -135,7 +135,7 @@ void resize_k(const uint8_t* __restrict__ src, int spitch, long long sfstride,
 #pragma unroll
             for (int k = 0; k < RS_LDS_DW / 256; k++) {
                 const int i = tid + 256 * k;
-                v[k] = i < n ? sb32[(sy_lo + r) * spitch_dw + min(sxa / 4 + c, max_dw)] : 0u;
+                v[k] = i < n ? sb32[(unsigned)((sy_lo + r) * spitch_dw + min(sxa / 4 + c, max_dw))] : 0u;
                 c += ms; r += qs;
                 if (c >= ndw) { c -= ndw; r++; }
             }
@@ -169,14 +169,16 @@ void resize_k(const uint8_t* __restrict__ src, int spitch, long long sfstride,
             const int y = y0 + ty * 2 + r;
             if (y >= dh) break;
             const int4 yt = ytab[y]; // {sy0, sy1, b0, b1}
-            const uint2 ha = *reinterpret_cast<const uint2*>(&s_h[((yt.x - sy_lo) * RS_TW + tx * 4) / 2]);
-            const uint2 hb = *reinterpret_cast<const uint2*>(&s_h[((yt.y - sy_lo) * RS_TW + tx * 4) / 2]);
-            const uint32_t h0[4] = { ha.x & 0xFFFFu, ha.x >> 16, ha.y & 0xFFFFu, ha.y >> 16 };
-            const uint32_t h1[4] = { hb.x & 0xFFFFu, hb.x >> 16, hb.y & 0xFFFFu, hb.y >> 16 };
+            const uint16_t* ha = reinterpret_cast<const uint16_t*>(s_h) + (yt.x - sy_lo) * RS_TW + tx * 4; // u16 reads: no unpacking
+            const uint16_t* hb = reinterpret_cast<const uint16_t*>(s_h) + (yt.y - sy_lo) * RS_TW + tx * 4;
             uint32_t out = 0;
 #pragma unroll
             for (int i = 0; i < 4; i++) { // v <= 255: no masking needed
-                const uint32_t v = ((((uint32_t)yt.z * h0[i]) >> 16) + (((uint32_t)yt.w * h1[i]) >> 16) + 2u) >> 2;
+                const uint32_t A = (uint32_t)yt.z * ha[i], Bv = (uint32_t)yt.w * hb[i];
+                // (A >> 16) + (Bv >> 16) + 2: high halves gathered by one v_perm, summed by v_dot2_u32_u16 with weights (1, 1)
+                typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+                const uint32_t hh = __builtin_amdgcn_perm(Bv, A, 0x07060302u);
+                const uint32_t v = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, hh), (us2){1, 1}, 2u, false) >> 2;
                 out |= v << (8 * i);
             }
             *reinterpret_cast<uint32_t*>(db + (size_t)y * dpitch + x4) = out;
