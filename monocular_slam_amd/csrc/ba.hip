@@ -49,6 +49,7 @@ struct BaDev {
     const int32_t* rowptr; const int32_t* blk_edge; const int32_t* slot;
     double* err; double* chi2; double* rho1; double* Hpp; double* Hll; double* Hpl_val; double* b;
     double* pt_rho;           // [n_points] robust chi2 per point
+    double* chi_part;         // [ceil(n_points / 4096)] slice sums of pt_rho (large problems)
     double* pose_part;        // [n_free][n_chunks_max][27]
     double* robust_chi2;      // [1]
     // ---- Schur complement (f1): reduced pose system S x_p = b_s, landmark back-substitution
@@ -215,28 +216,53 @@ void ba_poses_k(BaDev d)
     if (tid < 27) d.pose_part[((size_t)f * d.n_chunks_max + chunk) * 27 + tid] = s_red[tid * POSE_CHUNK];
 }
 
+// Final reductions.  Small problems (one local-BA window): ONE workgroup does both the per-pose chunk sums and the
+// robust chi2.  Large ones (many windows concatenated block-diagonally): ba_final_k runs as a grid -- workgroups
+// [0, n_pose_wg) take 256 (pose, value) items each, the rest reduce fixed 4096-point slices of pt_rho into chi_part --
+// and ba_final2_k adds the slice sums in index order.  Every sum has a fixed shape: bit-identical run to run.
+constexpr int CHI_SLICE = 4096;
 __global__ __launch_bounds__(256)
-void ba_final_k(BaDev d)
+void ba_final_k(BaDev d, int n_pose_wg)
 {
     const int tid = threadIdx.x;
-    // poses: one thread per (pose, value)
-    for (int i = tid; i < d.n_free * 27; i += 256) {
-        const int f = i / 27, q = i % 27;
-        const int nch = (d.rowptr[f + 1] - d.rowptr[f] + POSE_CHUNK - 1) / POSE_CHUNK;
-        double s = 0.0;
-        for (int c = 0; c < nch; c++) s += d.pose_part[((size_t)f * d.n_chunks_max + c) * 27 + q];
-        if (q < 21) {
-            int a = 0, rem = q; // unpack upper-triangle index
-            while (rem >= 6 - a) { rem -= 6 - a; a++; }
-            const int c2 = a + rem;
-            d.Hpp[(size_t)f * 36 + a * 6 + c2] = s;
-            d.Hpp[(size_t)f * 36 + c2 * 6 + a] = s;
-        } else d.b[6 * f + (q - 21)] = s;
+    const bool single = gridDim.x == 1;
+    if (single || (int)blockIdx.x < n_pose_wg) {
+        // poses: one thread per (pose, value)
+        const int i0 = single ? tid : (int)blockIdx.x * 256 + tid, step = single ? 256 : d.n_free * 27;
+        for (int i = i0; i < d.n_free * 27; i += step) {
+            const int f = i / 27, q = i % 27;
+            const int nch = (d.rowptr[f + 1] - d.rowptr[f] + POSE_CHUNK - 1) / POSE_CHUNK;
+            double s = 0.0;
+            for (int c = 0; c < nch; c++) s += d.pose_part[((size_t)f * d.n_chunks_max + c) * 27 + q];
+            if (q < 21) {
+                int a = 0, rem = q; // unpack upper-triangle index
+                while (rem >= 6 - a) { rem -= 6 - a; a++; }
+                const int c2 = a + rem;
+                d.Hpp[(size_t)f * 36 + a * 6 + c2] = s;
+                d.Hpp[(size_t)f * 36 + c2 * 6 + a] = s;
+            } else d.b[6 * f + (q - 21)] = s;
+        }
+        if (!single) return;
     }
-    // robust chi2: fixed-order tree over points
+    // robust chi2: fixed-order tree over points (all of them, or this workgroup's slice)
     __shared__ double s_r[256];
+    const int slice = single ? 0 : (int)blockIdx.x - n_pose_wg;
+    const int p0 = single ? 0 : slice * CHI_SLICE, p1 = single ? d.n_points : min(d.n_points, p0 + CHI_SLICE);
     double r = 0.0;
-    for (int i = tid; i < d.n_points; i += 256) r += d.pt_rho[i];
+    for (int i = p0 + tid; i < p1; i += 256) r += d.pt_rho[i];
+    s_r[tid] = r;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (tid < o) s_r[tid] += s_r[tid + o]; __syncthreads(); }
+    if (tid == 0) (single ? d.robust_chi2 : d.chi_part + slice)[0] = s_r[0];
+}
+
+__global__ __launch_bounds__(256)
+void ba_final2_k(BaDev d, int n_slices)
+{
+    __shared__ double s_r[256];
+    const int tid = threadIdx.x;
+    double r = 0.0;
+    for (int i = tid; i < n_slices; i += 256) r += d.chi_part[i];
     s_r[tid] = r;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) { if (tid < o) s_r[tid] += s_r[tid + o]; __syncthreads(); }
@@ -483,7 +509,7 @@ int mslam_ba_plan_create(mslam_ctx* ctx, const mslam_ba_problem* p, mslam_ba_pla
                  o_err = reserve(sizeof(double) * 2 * E), o_chi = reserve(sizeof(double) * E), o_rho = reserve(sizeof(double) * E),
                  o_hpp = reserve(sizeof(double) * 36 * std::max(nf, 1)), o_hll = reserve(sizeof(double) * 9 * NL),
                  o_hpl = reserve(sizeof(double) * 18 * std::max(nnzb, 1)), o_b = reserve(sizeof(double) * (6 * nf + 3 * NL)),
-                 o_ptr = reserve(sizeof(double) * NL), o_pp = reserve(sizeof(double) * 27 * (size_t)std::max(nf, 1) * n_chunks_max),
+                 o_ptr = reserve(sizeof(double) * NL), o_chp = reserve(sizeof(double) * ((size_t)NL / 4096 + 1)), o_pp = reserve(sizeof(double) * 27 * (size_t)std::max(nf, 1) * n_chunks_max),
                  o_rc = reserve(sizeof(double));
     // Schur scratch (dense pose-row x point lookup: fine for local-BA sizes; skipped when it would be huge)
     const bool want_schur = (size_t)nf * NL <= ((size_t)1 << 26) && nf > 0 && nnzb > 0;
@@ -522,7 +548,7 @@ int mslam_ba_plan_create(mslam_ctx* ctx, const mslam_ba_problem* p, mslam_ba_pla
     d.rowptr = (int32_t*)(base + o_row); d.blk_edge = (int32_t*)(base + o_be); d.slot = (int32_t*)(base + o_slot);
     d.err = (double*)(base + o_err); d.chi2 = (double*)(base + o_chi); d.rho1 = (double*)(base + o_rho);
     d.Hpp = (double*)(base + o_hpp); d.Hll = (double*)(base + o_hll); d.Hpl_val = (double*)(base + o_hpl); d.b = (double*)(base + o_b);
-    d.pt_rho = (double*)(base + o_ptr); d.pose_part = (double*)(base + o_pp); d.robust_chi2 = (double*)(base + o_rc);
+    d.pt_rho = (double*)(base + o_ptr); d.chi_part = (double*)(base + o_chp); d.pose_part = (double*)(base + o_pp); d.robust_chi2 = (double*)(base + o_rc);
     pl->d_poses = (double*)(base + o_poses); pl->d_points = (double*)(base + o_points);
     pl->d_rowptr = (int32_t*)(base + o_row); pl->d_col = (int32_t*)(base + o_col);
     pl->h_rowptr = rowptr; pl->h_col = col;
@@ -597,7 +623,13 @@ int mslam_ba_plan_build_dev(mslam_ba_plan* pl)
     LAUNCH(ctx, K_BA_POINTS, ba_points_k, dim3((d.n_points + groups_per_block - 1) / groups_per_block), dim3(BA_THREADS), 0, d);
     if (d.n_free > 0 && d.nnzb > 0)
         LAUNCH(ctx, K_BA_POSES, ba_poses_k, dim3(d.n_chunks_max, d.n_free), dim3(POSE_CHUNK), 0, d);
-    LAUNCH(ctx, K_BA_FINAL, ba_final_k, dim3(1), dim3(256), 0, d);
+    if (d.n_points <= 2 * CHI_SLICE && d.n_free * 27 <= 4096) {
+        LAUNCH(ctx, K_BA_FINAL, ba_final_k, dim3(1), dim3(256), 0, d, 0);
+    } else {
+        const int n_pose_wg = (d.n_free * 27 + 255) / 256, n_slices = (d.n_points + CHI_SLICE - 1) / CHI_SLICE;
+        LAUNCH(ctx, K_BA_FINAL, ba_final_k, dim3(n_pose_wg + n_slices), dim3(256), 0, d, n_pose_wg);
+        LAUNCH(ctx, K_BA_FINAL, ba_final2_k, dim3(1), dim3(256), 0, d, n_slices);
+    }
     HIP_TRY(ctx, hipGetLastError());
     return MSLAM_OK;
 }

@@ -252,3 +252,22 @@ def rigid_sequence(w: int, h: int, seed: int, n_frames: int = 3, K: np.ndarray =
         frames.append(render_view(a, depth, K, R, t))
         poses.append((R, t))
     return np.stack(frames), poses, depth
+
+
+def ba_concat(problems):
+    """Several independent BA problems as one block-diagonal problem (pose / point indices offset): what a batched
+    local BA over many streams hands to one mslam_ba_plan."""
+    out = {}
+    po = pt = 0
+    ep, el = [], []
+    for q in problems:
+        ep.append(q["edge_pose"] + po); el.append(q["edge_point"] + pt)
+        po += q["n_poses"]; pt += q["n_points"]
+    for k in ("poses", "pose_fixed", "points", "obs", "info", "intr"):
+        out[k] = np.ascontiguousarray(np.concatenate([q[k] for q in problems]))
+    for k in ("poses_gt", "points_gt"):
+        if all(k in q for q in problems):
+            out[k] = np.concatenate([q[k] for q in problems])
+    out.update(edge_pose=np.concatenate(ep).astype(np.int32), edge_point=np.concatenate(el).astype(np.int32),
+               n_poses=po, n_points=pt, n_edges=int(sum(q["n_edges"] for q in problems)), huber_delta=problems[0]["huber_delta"])
+    return out

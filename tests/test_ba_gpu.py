@@ -108,3 +108,25 @@ def test_schur_complement_and_back_substitution(ctx, oracle, n_poses, n_points, 
     plan.points_snapshot_dev(True)
     np.testing.assert_array_equal(plan.get_state()[1], X0)
     plan.close()
+
+
+def test_block_diagonal_batch_of_windows(ctx, oracle):
+    """Several local-BA windows as one block-diagonal problem (one launch per build): the grid form of the final
+    reductions (more than 8192 points) gives the oracle's system and every window's blocks equal its stand-alone build."""
+    parts = [synth.ba_problem(6, 3000, 70 + i) for i in range(4)]
+    pr = synth.ba_concat(parts)
+    assert pr["n_points"] == 12000
+    g, o = ctx.ba_build(pr), oracle.ba_build(pr)
+    _cmp(g, o)
+    plan = api.BaPlan(ctx, pr)
+    plan.build_dev(); a = plan.download()
+    plan.build_dev(); b = plan.download()
+    for k in ("Hpp", "Hll", "Hpl_val", "b"):
+        assert np.array_equal(a[k], b[k]), k
+    assert a["robust_chi2"] == b["robust_chi2"]
+    plan.close()
+    # window 2 alone: same Hll / chi2 values (its points do not see the other windows)
+    alone = ctx.ba_build(parts[2])
+    lo = sum(p["n_points"] for p in parts[:2])
+    np.testing.assert_array_equal(g["Hll"][lo:lo + parts[2]["n_points"]], alone["Hll"])
+    assert abs(sum(ctx.ba_build(p)["robust_chi2"] for p in parts) - g["robust_chi2"]) <= 1e-9 * g["robust_chi2"]

@@ -109,6 +109,13 @@ def main():
     E = pr["n_edges"]
     out["C3 BA build 10x5000"] = dict(unit="builds/s", gpu=1 / t, cpu=1 / tc, alg_bytes=216 * E, gpu_edges_per_s=E / t, edges=E)
     plan.close()
+    # ---- C3 x B: B independent local-BA windows (one per stream) as ONE block-diagonal problem -> one build per launch
+    prB = synth.ba_concat([synth.ba_problem(10, 5000, 4004 + i) for i in range(B)])
+    planB = api.BaPlan(ctx, prB)
+    t = gpu_time(ctx, planB.build_dev, reps=20, tag='ba_x%d' % B)
+    EB = prB["n_edges"]
+    out["C3 BA build, %d windows per launch" % B] = dict(unit="builds/s", gpu=B / t, cpu=1 / tc, alg_bytes=216 * EB / B, gpu_edges_per_s=EB / t, edges=EB)
+    planB.close()
     for k, v in out.items():
         v["gpu_alg_GBps"] = v["gpu"] * v["alg_bytes"] / 1e9
         v["frac_of_8TBps"] = v["gpu_alg_GBps"] / 8000.0
