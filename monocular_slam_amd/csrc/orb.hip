@@ -118,31 +118,29 @@ void resize_k(const uint8_t* __restrict__ src, int spitch, long long sfstride,
     const int sy_lo = ytab[y0].x, sy_hi = ytab[yl].y;
     const int sxa = sx_lo & ~3;
     const int ndw = ((sx_hi - sxa) >> 2) + 1, nrows = sy_hi - sy_lo + 1;
-    const bool use_lds = ndw * nrows < RS_LDS_DW && nrows <= RS_HROWS; // true for pyramid scales up to ~1.6
+    const bool use_lds = ndw * nrows < RS_LDS_DW && nrows <= RS_HROWS && ndw <= 128; // true for pyramid scales up to ~1.6
     const uint8_t* sb = src + b * sfstride;
     const int tx = tid & 63, ty = tid >> 6;
     const int x4 = x0 + tx * 4;
     uint8_t* db = dst + b * dfstride;
     if (use_lds) {
-        {   // stage the footprint; all loads of a lane are issued before the first LDS store (one memory latency, not one per pass)
+        {   // stage the footprint: 128 lanes per source row, two rows per pass, RS_HROWS / 2 passes; all loads of a lane are
+            // issued before its first LDS store (one memory latency per tile, not one per pass)
             const int max_dw = spitch / 4 - 1, spitch_dw = spitch / 4;
             const uint32_t* sb32 = reinterpret_cast<const uint32_t*>(sb);
-            const int n = ndw * nrows; // < RS_LDS_DW = 6 * 256
-            uint32_t v[RS_LDS_DW / 256];
-            // (row, column) of element tid + 256 k without a division per element: one division, then steps of 256
-            const int qs = 256 / ndw, ms = 256 - qs * ndw; // wave-uniform
-            int r = tid / ndw, c = tid - r * ndw;
+            const int c = tid & 127, rh = tid >> 7;
+            const unsigned col = (unsigned)min(sxa / 4 + c, max_dw);
+            const bool c_ok = c < ndw;
+            uint32_t v[RS_HROWS / 2];
 #pragma unroll
-            for (int k = 0; k < RS_LDS_DW / 256; k++) {
-                const int i = tid + 256 * k;
-                v[k] = i < n ? sb32[(unsigned)((sy_lo + r) * spitch_dw + min(sxa / 4 + c, max_dw))] : 0u;
-                c += ms; r += qs;
-                if (c >= ndw) { c -= ndw; r++; }
+            for (int k = 0; k < RS_HROWS / 2; k++) {
+                const int r = 2 * k + rh;
+                v[k] = (c_ok && r < nrows) ? sb32[(unsigned)((sy_lo + r) * spitch_dw) + col] : 0u;
             }
 #pragma unroll
-            for (int k = 0; k < RS_LDS_DW / 256; k++) {
-                const int i = tid + 256 * k;
-                if (i < n) s_src[i] = v[k];
+            for (int k = 0; k < RS_HROWS / 2; k++) {
+                const int r = 2 * k + rh;
+                if (c_ok && r < nrows) s_src[r * ndw + c] = v[k];
             }
         }
         __syncthreads();
