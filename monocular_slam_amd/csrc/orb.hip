@@ -219,27 +219,9 @@ __device__ __forceinline__ int ring_ofs(int k)
     return dy[k] * FP_PITCH + dx[k];
 }
 
-// exact cornerScore<16>: max over the 16 arcs of 9 of min(d) / min(-d), minus 1
-__device__ __forceinline__ int fast_exact_score(const int* d)
-{
-    int m2[16], m4[16], m8[16];
-    int n2[16], n4[16], n8[16];
-#pragma unroll
-    for (int k = 0; k < 16; k++) { m2[k] = min(d[k], d[(k + 1) & 15]); n2[k] = max(d[k], d[(k + 1) & 15]); }
-#pragma unroll
-    for (int k = 0; k < 16; k++) { m4[k] = min(m2[k], m2[(k + 2) & 15]); n4[k] = max(n2[k], n2[(k + 2) & 15]); }
-#pragma unroll
-    for (int k = 0; k < 16; k++) { m8[k] = min(m4[k], m4[(k + 4) & 15]); n8[k] = max(n4[k], n4[(k + 4) & 15]); }
-    int amax = -256, bmin = 256;
-#pragma unroll
-    for (int k = 0; k < 16; k++) {
-        amax = max(amax, min(m8[k], d[(k + 8) & 15]));
-        bmin = min(bmin, max(n8[k], d[(k + 8) & 15]));
-    }
-    return max(amax, -bmin) - 1;
-}
-
-// The same on packed 16-bit pairs D[k] = (d[k], d[k + 8]), k = 0..7 (|d| <= 255): v_pk_min/max_i16 work on two ring positions
+// exact cornerScore<16>: max over the 16 arcs of 9 of min(d) / min(-d), minus 1, with d[k] = centre - ring pixel k
+// (AND-doubling over the ring: minima of 2, 4, 8 consecutive, then the 9th).  Evaluated on packed 16-bit pairs
+// D[k] = (d[k], d[k + 8]), k = 0..7 (|d| <= 255): v_pk_min/max_i16 work on two ring positions
 // per instruction and the "+8" partner of a pair is a half swap, which the VOP3P op_sel modifiers provide for free.
 typedef short s2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ s2v swp(s2v a) { return __builtin_shufflevector(a, a, 1, 0); }
@@ -641,9 +623,22 @@ void describe_k(OrbDev od, DescArgs out)
     const int xa = px0 & ~3, xo = px0 & 3;
     const int max_dw = lv.pitch / 4 - 1;
     uint32_t* raw32 = s_raw[wave];
-    for (int i = lane; i < DP_N * DP_ROW_DW; i += 64) {
-        int r = i / DP_ROW_DW, c = i % DP_ROW_DW;
-        raw32[r * (DP_PITCH / 4) + c] = active ? reinterpret_cast<const uint32_t*>(img + (size_t)(py0 + r) * lv.pitch)[min(xa / 4 + c, max_dw)] : 0u;
+    {   // 5 rows x 12 dwords per pass (60 of 64 lanes), 9 passes; loads first, then the LDS stores
+        const int r0 = lane / DP_ROW_DW, c = lane - r0 * DP_ROW_DW;
+        const uint32_t* img32 = reinterpret_cast<const uint32_t*>(img);
+        const int pitch_dw = lv.pitch / 4;
+        const unsigned col = (unsigned)min(xa / 4 + c, max_dw);
+        uint32_t v[9];
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+            const int r = r0 + 5 * k;
+            v[k] = (active && lane < 60 && r < DP_N) ? img32[(unsigned)((py0 + r) * pitch_dw) + col] : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+            const int r = r0 + 5 * k;
+            if (lane < 60 && r < DP_N) raw32[r * (DP_PITCH / 4) + c] = v[k];
+        }
     }
     __syncthreads();
     const uint8_t* raw = reinterpret_cast<const uint8_t*>(raw32) + xo; // raw[r*DP_PITCH + c], centre at (21,21)
@@ -669,8 +664,9 @@ void describe_k(OrbDev od, DescArgs out)
     uint32_t* hT = s_h[wave];
     {
         const uint32_t GA = 18u | (34u << 8) | (49u << 16) | (55u << 24), GB = 49u | (34u << 8) | (18u << 16);
-        for (int i = lane; i < DH_RP * DH_CG; i += 64) {
-            const int rp = i / DH_CG, cg = i - rp * DH_CG;
+        int rp = lane / DH_CG, cg = lane - rp * DH_CG; // item = rp * DH_CG + cg advances by 64 = 6 * DH_CG + 4
+        for (int i = lane; i < DH_RP * DH_CG; i += 64, rp += 6, cg += 4) {
+            if (cg >= DH_CG) { cg -= DH_CG; rp++; }
             uint32_t h[2][4];
 #pragma unroll
             for (int dr = 0; dr < 2; dr++) {
@@ -695,8 +691,10 @@ void describe_k(OrbDev od, DescArgs out)
         typedef unsigned short us2 __attribute__((ext_vector_type(2)));
         const us2 G01 = {18, 34}, G23 = {49, 55}, G45 = {49, 34}, G6l = {18, 0}, G6h = {0, 18};
 #define DOT2(P, G, C) __builtin_amdgcn_udot2(__builtin_bit_cast(us2, (P)), (G), (C), false)
-        for (int i = lane; i < DB_N * DV_RG; i += 64) {
-            const int rg = i / DB_N, c = i - rg * DB_N;
+        static_assert(DH_CG == 10 && DB_N == 37, "item steps below assume these sizes");
+        int rg = lane / DB_N, c = lane - rg * DB_N; // item = rg * DB_N + c advances by 64 = DB_N + 27
+        for (int i = lane; i < DB_N * DV_RG; i += 64, rg += 1, c += 27) {
+            if (c >= DB_N) { c -= DB_N; rg++; }
             const uint32_t* q = hT + c * HT_DW + 2 * rg;
             const uint32_t p0 = q[0], p1 = q[1], p2 = q[2], p3 = q[3], p4 = q[4];
             const uint32_t q0 = __builtin_amdgcn_alignbyte(p1, p0, 2), q1 = __builtin_amdgcn_alignbyte(p2, p1, 2),
