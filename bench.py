@@ -28,6 +28,7 @@ sys.path.insert(0, ROOT)
 W, H, NFEAT = 1920, 1080, 2000
 PNP_P, PNP_H, PNP_THR = 2000, 4096, 2.0
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+VALU_ISSUE_PEAK_G = 256 * 4 * 2.4 / 4  # G wave-instructions/s: 256 CUs x 4 SIMDs, one wave64 VALU op per 4 clocks at 2.4 GHz
 
 # algorithmic bytes per unit: extract W*H + 56*N; match 32*(Nq+Nt) + 16*Nq;
 # PnP 40*P + 4*s*H + 48 + P + 4*H
@@ -236,16 +237,21 @@ def main():
                 alg_k = ALG_BYTES[u] * B / lps
                 dur_ms = per[kname] if dur_ms is None else dur_ms
                 ach = alg_k / (dur_ms * 1e-3) / 1e9
-                tr = None
+                tr = valu = None
                 if os.path.exists(pmc_path):
                     try:  # PMC passes were collected at 32 frames per launch: only comparable per launch at that size
                         pmc = json.load(open(pmc_path))
                         if int(pmc.get("_batch", 32)) == SB and world == 1:
                             tr = pmc.get(kname, {}).get("hbm_bytes_per_launch")
+                            valu = pmc.get(kname, {}).get("valu_insts_per_launch")
                     except Exception:
-                        tr = None
-                return {"bound": "hbm", "kernel": kname, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                        "traffic": tr, "algorithmic_bytes_per_launch": alg_k, "avg_launch_ms": dur_ms, "unit_priced": u}
+                        tr = valu = None
+                out_r = {"bound": "hbm", "kernel": kname, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                         "traffic": tr, "algorithmic_bytes_per_launch": alg_k, "avg_launch_ms": dur_ms, "unit_priced": u}
+                if valu is not None:  # what actually bounds these kernels: wave-instruction issue (1024 SIMDs, one VALU op per 4 clocks at 2.4 GHz)
+                    out_r["valu_issue"] = {"achieved": valu / (dur_ms * 1e-3) / 1e9, "peak": VALU_ISSUE_PEAK_G, "unit": "G wave-instr/s",
+                                           "frac": valu / (dur_ms * 1e-3) / 1e9 / VALU_ISSUE_PEAK_G, "valu_insts_per_launch": valu}
+                return out_r
 
             out["roofline"] = roof(dom)
             out["roofline"]["note"] = ("algorithmic bytes (SURVEY 8d) of the %s unit x %d frames per launch; launch duration measured with HIP "

@@ -14,6 +14,9 @@ out = {"_batch": 32, "_source": "profiles/r01_pmc_summary_default_bench.json (to
 for k, v in summ.items():
     if "FETCH_SIZE" in v and "WRITE_SIZE" in v and not k.startswith("__amd"):
         out[k] = {"hbm_bytes_per_launch": (2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024.0, "FETCH_SIZE_KiB": v["FETCH_SIZE"],
-                  "WRITE_SIZE_KiB": v["WRITE_SIZE"], "avg_ns": v.get("avg_ns")}
+                  "WRITE_SIZE_KiB": v["WRITE_SIZE"], "avg_ns": v.get("avg_ns"),
+                  # wave-level instruction counts per launch (SQ_INSTS_*): the issue-side roofline of bench.py
+                  "valu_insts_per_launch": v.get("SQ_INSTS_VALU"), "salu_insts_per_launch": v.get("SQ_INSTS_SALU"),
+                  "lds_insts_per_launch": v.get("SQ_INSTS_LDS")}
 json.dump(out, open(sys.argv[2], "w"), indent=1, sort_keys=True)
 print("wrote", sys.argv[2])
