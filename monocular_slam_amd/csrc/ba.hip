@@ -179,7 +179,7 @@ void ba_poses_k(BaDev d)
     const int k0 = d.rowptr[f], k1 = d.rowptr[f + 1];
     const int k = k0 + chunk * POSE_CHUNK + tid;
     if (k0 + chunk * POSE_CHUNK >= k1) return; // whole block out of range
-    __shared__ double s_red[27 * POSE_CHUNK];
+    __shared__ double s_red[27 * (POSE_CHUNK / 64)];
     double v[27];
 #pragma unroll
     for (int q = 0; q < 27; q++) v[q] = 0.0;
@@ -204,16 +204,22 @@ void ba_poses_k(BaDev d)
 #pragma unroll
         for (int a = 0; a < 6; a++) v[21 + a] = L.B[a] * r0 + L.B[6 + a] * r1;
     }
+    // fixed-shape reduction: xor butterfly inside each wavefront (registers), then the 4 wavefront sums in index order
+    // (replaces a 55 KiB LDS tree that allowed only two workgroups per CU)
 #pragma unroll
-    for (int q = 0; q < 27; q++) s_red[q * POSE_CHUNK + tid] = v[q];
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+        for (int q = 0; q < 27; q++) v[q] += __shfl_xor(v[q], o);
+    if ((tid & 63) == 0)
+#pragma unroll
+        for (int q = 0; q < 27; q++) s_red[q * (POSE_CHUNK / 64) + (tid >> 6)] = v[q];
     __syncthreads();
-    for (int o = POSE_CHUNK / 2; o > 0; o >>= 1) {
-        if (tid < o)
+    if (tid < 27) {
+        double t = s_red[tid * (POSE_CHUNK / 64)];
 #pragma unroll
-            for (int q = 0; q < 27; q++) s_red[q * POSE_CHUNK + tid] += s_red[q * POSE_CHUNK + tid + o];
-        __syncthreads();
+        for (int w = 1; w < POSE_CHUNK / 64; w++) t += s_red[tid * (POSE_CHUNK / 64) + w];
+        d.pose_part[((size_t)f * d.n_chunks_max + chunk) * 27 + tid] = t;
     }
-    if (tid < 27) d.pose_part[((size_t)f * d.n_chunks_max + chunk) * 27 + tid] = s_red[tid * POSE_CHUNK];
 }
 
 // Final reductions.  Small problems (one local-BA window): ONE workgroup does both the per-pose chunk sums and the
