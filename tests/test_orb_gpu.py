@@ -115,3 +115,32 @@ def test_batched_device_extract(ctx, oracle):
     for b in range(B):
         ko, do = oracle.orb_extract(frames[b], _oracle_params(oracle, p), cap=8192)
         _same_keypoints(kall[b, : n[b]], dall[b, : n[b]], ko, do)
+
+
+def test_4k_frame_and_wide_scale_factors(oracle):
+    """Largest frame class (3840x2160, own context) and pyramid scale factors whose tile footprint exceeds the LDS form of
+    resize_k (generic path), plus a mostly flat frame with a few textured islands (sparse FAST survivor lists)."""
+    with api.Context(device=0, max_w=3840, max_h=2160, max_kpts=8192, batch=1) as c4:
+        img = synth.textured_frame(3840, 2160, 4242)
+        p = api.default_orb_params(4000)
+        kg, dg = c4.orb_extract(img, p)
+        ko, do = oracle.orb_extract(img, _oracle_params(oracle, p), cap=16384)
+        assert len(ko) > 3000
+        _same_keypoints(kg, dg, ko, do)
+        small = synth.textured_frame(1280, 720, 99)
+        for sf, nl in ((1.7, 5), (2.0, 4), (1.05, 3)):
+            q = api.default_orb_params(800)
+            q.scale_factor, q.nlevels = sf, nl
+            kg, dg = c4.orb_extract(small, q)
+            ko, do = oracle.orb_extract(small, _oracle_params(oracle, q), cap=8192)
+            assert len(ko) > 200, sf
+            _same_keypoints(kg, dg, ko, do)
+        flat = np.full((1080, 1920), 90, np.uint8)
+        rng = np.random.default_rng(8)
+        for _ in range(12):
+            y, x = int(rng.integers(60, 900)), int(rng.integers(60, 1700))
+            flat[y:y + 96, x:x + 128] = synth.textured_frame(128, 96, int(rng.integers(1, 1000)))
+        kg, dg = c4.orb_extract(flat, api.default_orb_params(1000))
+        ko, do = oracle.orb_extract(flat, _oracle_params(oracle, api.default_orb_params(1000)), cap=8192)
+        assert 100 < len(ko)
+        _same_keypoints(kg, dg, ko, do)
