@@ -45,14 +45,14 @@ __constant__ int c_umax[16] = { 15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 
 // 7x7 sigma=2 Gaussian, 8-bit fixed point (getGaussianKernel(7,2,CV_32F) * 256, cvRound)
 __constant__ int c_gk[7] = { 18, 34, 49, 55, 49, 34, 18 };
 
-// FAST tile geometry: the SCORE region (outputs + 1 px ring for NMS) is 128 x 32 so that a row of it is 32 groups of
-// 4 pixels = 32 LDS dwords; outputs are the inner 126 x 30.  The pixel tile (score region + 3 px ring) is staged so
+// FAST tile geometry: the SCORE region (outputs + 1 px ring for NMS) is 128 x 64 so that a row of it is 32 groups of
+// 4 pixels = 32 LDS dwords; outputs are the inner 126 x 62.  The pixel tile (score region + 3 px ring) is staged so
 // that score column 0 sits on a dword boundary: LDS byte (c + 1) of a row holds tile column c.
-constexpr int FS_W = 128, FS_H = 32;              // score region
-constexpr int FT_W = FS_W - 2, FT_H = FS_H - 2;   // outputs per tile (126 x 30)
-constexpr int FP_H = FS_H + 6;                    // pixel tile rows (38)
+constexpr int FS_W = 128, FS_H = 64;              // score region
+constexpr int FT_W = FS_W - 2, FT_H = FS_H - 2;   // outputs per tile (126 x 62)
+constexpr int FP_H = FS_H + 6;                    // pixel tile rows (70)
 constexpr int FP_PITCH = 136;                     // LDS row pitch in bytes (34 dwords: 134 columns + 2 pad)
-constexpr int FAST_THREADS = 256;
+constexpr int FAST_THREADS = 512;                 // 128 x 64 tiles with 8 wavefronts: 0.273 -> 0.260 ms vs 128 x 32 / 4 (128 x 128 / 16: 0.275)
 constexpr int CNT_STRIDE = 32;                    // candidate counters one per 128-byte line: tiles of different
                                                   // (frame, level) pairs must not serialise on one L2 atomic unit
 
@@ -262,7 +262,7 @@ void fast_nms_k(OrbDev od)
     __shared__ uint8_t s_score[FS_H * FS_W];
     __shared__ uint16_t s_list[FS_H * FS_W];
     __shared__ int s_n1, s_ne, s_base;
-    // NMS maxima (<= 63 x 15 per tile) are collected in the pixel tile's storage, which is dead after phase 2
+    // NMS maxima (<= 63 x 31 per tile) are collected in the pixel tile's storage, which is dead after phase 2
     uint32_t* s_emit = s_pix;
     static_assert(((FT_W + 1) / 2) * ((FT_H + 1) / 2) * 4 <= FP_H * FP_PITCH, "emit buffer must fit in the pixel tile");
 
@@ -323,8 +323,8 @@ void fast_nms_k(OrbDev od)
 #pragma unroll
         for (int k = 0; k < 4; k++) colok[k] = __builtin_amdgcn_ballot_w64(4 * g + k < lim_x);
 #pragma unroll
-        for (int m = 0; m < FS_H / 8; m++) {
-            const int sy = ry + 8 * m;
+        for (int m = 0; m < FS_H / (FAST_THREADS / 32); m++) {
+            const int sy = ry + (FAST_THREADS / 32) * m;
             const unsigned long long rowok = __builtin_amdgcn_ballot_w64(sy < lim_y);
             const uint32_t* rowp = s_pix + (sy + 3) * (FP_PITCH / 4) + g; // rows/columns exist in LDS for every lane
             const uint32_t Lw = rowp[0], Cw = rowp[1], Rw = rowp[2];
