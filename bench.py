@@ -93,7 +93,7 @@ def cpu_baseline(frames: np.ndarray, pnp, n_frames: int) -> dict:
     try:
         import subprocess
         ncpu = min(16, len(os.sched_getaffinity(0)))  # the one-GPU box's CPU share
-        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "cpu_baseline_mp.py"), str(ncpu), str(max(2, n_frames // 8))],
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "cpu_baseline_mp.py"), str(ncpu), str(max(2, n_frames // 8))],
                            capture_output=True, text=True, timeout=300)
         out["all_cores"] = json.loads(r.stdout.strip().splitlines()[-1])
     except Exception as e:  # informational only

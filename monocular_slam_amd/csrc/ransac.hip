@@ -763,7 +763,10 @@ __device__ __forceinline__ double quad_form(const double* D, const double* p, co
 
 __device__ __forceinline__ double sel3(const double* v, int i) { return i == 0 ? v[0] : (i == 1 ? v[1] : v[2]); }
 
-// P3P (see oracle/pnp.c for the derivation): up to 4 poses
+// P3P, up to 4 poses.  The three distance constraints  l_i^2 + l_j^2 - 2 (f_i.f_j) l_i l_j = |X_i - X_j|^2  span a pencil
+// of conics; a degenerate member (a real root of a cubic, by monotone Newton iteration) splits into two planes (3x3 Jacobi
+// eigen-decomposition), each intersected with another member of the pencil (a quadratic); depths are polished by 5
+// Gauss-Newton rounds and the pose follows from the two point triads.  Only + - * / sqrt: reproducible operation for operation.
 __device__ int p3p(const double* f, const double* X, double (*Rout)[9], double (*tout)[3])
 {
     const double* f0 = f; const double* f1 = f + 3; const double* f2 = f + 6;

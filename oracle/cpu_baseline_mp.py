@@ -9,7 +9,7 @@ import os
 import sys
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))  # oracle/ -> repo root
 sys.path.insert(0, ROOT)
 
 

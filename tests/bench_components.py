@@ -11,7 +11,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))  # tests/ -> repo root
 sys.path.insert(0, ROOT)
 from monocular_slam_amd import api, synth  # noqa: E402
 from monocular_slam_amd.tracking import TrackingBatch  # noqa: E402
