@@ -121,3 +121,24 @@ def test_fuzz_pnp_and_fmat(ctx, oracle, case):
         np.testing.assert_array_equal(g["counts"], o["counts"])
         np.testing.assert_array_equal(g["status"], o["status"])
         assert g["best_h"] == o["best_h"]
+
+
+@pytest.mark.parametrize("case", range(N))
+def test_fuzz_ba_build_and_schur(ctx, oracle, case):
+    rng = np.random.default_rng(3000 + case)
+    n_poses, n_points = int(rng.integers(2, 14)), int(rng.integers(5, 2500))
+    pr = synth.ba_problem(n_poses, n_points, 600 + case, obs_noise=float(rng.uniform(0, 3)), gross_frac=float(rng.uniform(0, 0.2)))
+    if rng.integers(0, 3) == 0:
+        pr["huber_delta"] = 0.0
+    extra_fixed = rng.random(n_poses) < 0.2
+    extra_fixed[-1] = False                                  # keep at least one free pose
+    pr["pose_fixed"] = np.maximum(pr["pose_fixed"], extra_fixed.astype(np.uint8))
+    perm = rng.permutation(pr["n_edges"])
+    for k in ("edge_pose", "edge_point", "obs", "info"):
+        pr[k] = np.ascontiguousarray(pr[k][perm])
+    g, o = ctx.ba_build(pr), oracle.ba_build(pr)
+    assert g["n_free_poses"] == o["n_free_poses"] and g["nnzb"] == o["nnzb"]
+    np.testing.assert_array_equal(g["Hpl_col"], o["Hpl_col"])
+    for k in ("err", "chi2", "rho1", "Hpp", "Hll", "Hpl_val", "b"):
+        assert np.abs(g[k] - o[k]).max() <= 1e-9 * max(1e-300, np.abs(o[k]).max()), k
+    assert abs(g["robust_chi2"] - o["robust_chi2"]) <= 1e-9 * abs(o["robust_chi2"])
