@@ -57,3 +57,36 @@ def max_over_ranks(value: float, dist=None, device=None) -> float:
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def sharded_pnp_ransac(ctx, X, x, K, dist_coeffs, samples, params, dist=None, device=None, rank=None, world=None):
+    """ONE PnP RANSAC problem with its hypotheses sharded over ranks (BASELINE config C4).
+
+    Every rank scores its contiguous slice of the sample table on its own GPU (`ctx.pnp_ransac`); with a process group the
+    int32 inlier counts are all-gathered (the only collective: <= 16 KiB).  `finish_sharded_pnp` then picks the same
+    global winner on every rank (max count, lowest global index -- `params.confidence` must be 0: the adaptive bound is
+    defined over the ordered full sequence) and refines it locally, so all ranks end with identical results and nothing
+    else is exchanged.  Passing `rank` / `world` without a process group rehearses one rank's share in a single process.
+    Returns (lo, hi, local_counts, all_counts or None).
+    """
+    assert params.confidence == 0.0, "sharded scoring uses the plain argmax rule"
+    samples = np.ascontiguousarray(samples, np.int32)
+    H = samples.shape[0]
+    grouped = dist is not None and dist.is_initialized() and dist.get_world_size() > 1 and rank is None
+    if grouped:
+        rank, world = dist.get_rank(), dist.get_world_size()
+    elif rank is None:
+        rank, world = 0, 1
+    lo, hi = shard_range(H, rank, world)
+    local = ctx.pnp_ransac(X, x, K, dist_coeffs, samples[lo:hi], params)["counts"] if hi > lo else np.zeros(0, np.int32)
+    if grouped:
+        return lo, hi, local, allgather_counts(local, H, dist, device)
+    return lo, hi, local, (local if world == 1 else None)
+
+
+def finish_sharded_pnp(ctx, X, x, K, dist_coeffs, samples, params, counts):
+    """Global winner over the gathered counts + its refinement (identical on every rank)."""
+    best, best_count = global_winner(np.asarray(counts))
+    out = ctx.pnp_ransac(X, x, K, dist_coeffs, np.ascontiguousarray(samples[best:best + 1], np.int32), params)
+    out.update(best_h=best if out["rc"] == 0 else -1, counts=np.asarray(counts, np.int32), winner_count=best_count)
+    return out

@@ -222,3 +222,25 @@ def test_fmat_threshold_shell(ctx, oracle):
     np.testing.assert_array_equal(g["counts"], o["counts"])
     np.testing.assert_array_equal(g["status"], o["status"])
     assert g["best_h"] == o["best_h"]
+
+
+def test_hypothesis_sharding_over_ranks_equals_the_unsharded_run(ctx, oracle):
+    """C4 / section 8e: one problem's hypotheses scored in 3 contiguous slices (as 3 ranks would), counts concatenated in
+    shard order (what the all-gather produces), global argmax, winner refined locally == the unsharded call."""
+    from monocular_slam_amd import distributed as D
+    pr = synth.pnp_problem(1500, 77)
+    S = synth.sample_table(1500, 1000, 4, 5)
+    p = api.default_pnp_params()
+    p.reproj_thr, p.confidence = 2.0, 0.0
+    full = ctx.pnp_ransac(pr["X"], pr["x"], pr["K"], pr["dist"], S, p)
+    parts = []
+    for r in range(3):
+        lo, hi, local, _ = D.sharded_pnp_ransac(ctx, pr["X"], pr["x"], pr["K"], pr["dist"], S, p, rank=r, world=3)
+        assert (lo, hi) == D.shard_range(1000, r, 3) and len(local) == hi - lo
+        parts.append(local)
+    counts = np.concatenate(parts)
+    np.testing.assert_array_equal(counts, full["counts"])
+    g = D.finish_sharded_pnp(ctx, pr["X"], pr["x"], pr["K"], pr["dist"], S, p, counts)
+    assert g["best_h"] == full["best_h"] and g["n_inliers"] == full["n_inliers"]
+    np.testing.assert_array_equal(g["inliers"], full["inliers"])
+    np.testing.assert_array_equal(g["Rt"], full["Rt"])      # same kernels on the same sample: bit-identical
