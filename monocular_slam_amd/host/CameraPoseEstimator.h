@@ -1,38 +1,3 @@
-// CameraPoseEstimator -- the reference's stage (src/CameraPoseEstimator.h:19-29, src/CameraPoseEstimator.cpp:517-530):
-// frame 0 gets the identity pose, frame 1 the two-view initialisation (:264-376), later frames PnP against the map
-// (:384-515).  Every OpenCV call of the reference is replaced by a C ABI call (match, F RANSAC, PnP RANSAC,
-// triangulation); essential-matrix decomposition, candidate vote and map bookkeeping stay host code, as in the reference.
-// `estimate` is the new entry point north_star names; process() calls it and appends to relative_frame_poses (:528).
-// The GUI call of the reference (drawEpipolarLine, :308-312, blocks on waitKey) is deliberately not reproduced.
+// forwards to Stages.h (all three stage classes are declared there)
 #pragma once
-#include "ProcessingNode.h"
-#include "Runtime.h"
-
-class CameraPoseEstimator : public ProcessingNode {
-public:
-    CameraPoseEstimator();
-    void estimate(DataManager& data, int frameIdx);
-    virtual void process(DataManager& data, int frameIdx) override;
-    virtual bool validationCheck(DataManager& data, int frameIdx) override;
-
-    // parameters; defaults are the reference's values
-    float ratioInitial = FEATURE_MATCH_RATIO_TEST;  // 0.85f (:280)
-    float ratioTracking = 0.8f;                     // matchFeatures default (:200, :409)
-    mslam_fmat_params fmat;                         // metric 1, MAX_DISTANCE 3.0, CONFIDENCE 0.85, CV_FM_8POINT refit (:563,:585)
-    int fmatHypotheses = 2000;                      // OpenCV's RANSAC iteration cap
-    mslam_pnp_params pnp;                           // 8 px (OpenCV 2.4 solvePnPRansac default)
-    int pnpHypotheses = 100;                        // OpenCV 2.4 default iterationsCount
-    double distCoeff[8];                            // TUM freiburg1 coefficients hard-coded by the reference (:462-469)
-    int numBackTraverse = 5;                        // (:388)
-    uint64_t seed = 0x5EEDull;                      // sample tables: xorshift64*(seed + frame index * 1000 + use)
-    int lastStatus = 0;                             // MSLAM_OK or the status that made the stage keep the previous pose
-
-private:
-    void setReferenceFramePose(DataManager& data, int frameIdx);
-    void initialPoseEstimation(DataManager& data, int frameIdx);
-    void pnpPoseEstimation(DataManager& data, int frameIdx);
-    void matchFeatures(const cv::Mat& d1, const cv::Mat& d2, std::vector<cv::DMatch>& matches, float ratio);
-    bool computeFundamentalMatrix(const std::vector<Point2d>& p1, const std::vector<Point2d>& p2, const std::vector<cv::DMatch>& matches,
-                                  std::vector<Point2d>& in1, std::vector<Point2d>& in2, double F[9], std::vector<unsigned char>& status,
-                                  uint64_t tableSeed);
-};
+#include "Stages.h"

@@ -1,6 +1,7 @@
 // The blackboard data model of the reference (src/MapPoint.h:16-28, src/Frame.h:22-72, src/DataManager.h:23-36),
 // re-stated with identical member names so that stage code written against the reference compiles against it.
 #pragma once
+#include <cassert>
 #include "Common.h"
 
 using cv::Mat;
@@ -14,9 +15,10 @@ public:
     MapPoint(Point3d worldPosition, int id) : id((long unsigned int)id), worldPosition(worldPosition) {}
     long unsigned int id;   // identifier (== index in DataManager::mapPoints)
     Point3d worldPosition;  // 3D world coordinate
-    void addObservingFrame(int frameIdx, int featureIdx);
-    int getFeatureIdxFromObservingFrame(int frameIdx);
-    void deleteObservingFrame(int frameIdx);
+    // observer bookkeeping (reference src/MapPoint.cpp:8-28): observing frame id -> feature index, -1 if not an observer
+    void addObservingFrame(int frameIdx, int featureIdx) { assert(featureIdx >= 0); observerToIndex[frameIdx] = featureIdx; }
+    int getFeatureIdxFromObservingFrame(int frameIdx) const { auto it = observerToIndex.find(frameIdx); return it == observerToIndex.end() ? -1 : it->second; }
+    void deleteObservingFrame(int frameIdx) { observerToIndex.erase(frameIdx); }
     const std::map<int, int>& observers() const { return observerToIndex; }
 private:
     std::map<int, int> observerToIndex; // observing frame id -> feature index in that frame
