@@ -104,8 +104,8 @@ def cpu_baseline(frames: np.ndarray, pnp, n_frames: int) -> dict:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=64, help="independent streams per GPU per step")
     ap.add_argument("--sub-batches", type=int, default=2, help="the batch is enqueued as this many sub-batches on separate HIP streams")
     ap.add_argument("--cpu-frames", type=int, default=24, help="frames of the cpu_baseline sample (0 = skip)")
