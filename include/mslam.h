@@ -80,6 +80,12 @@ int mslam_profile_kernel_count(void);
 const char* mslam_profile_kernel_name(int kid);
 int mslam_profile_read(mslam_ctx* ctx, double* total_ms, int32_t* launches);
 
+/* HIP graphs for launch-bound use (small batches, one stream): when enabled, the kernel chain of
+ * mslam_orb_extract_batch_dev is captured once per distinct argument set on this context and replayed with
+ * hipGraphLaunch afterwards (same kernels, same order, same results).  Off by default; MSLAM_GRAPHS=1 in the
+ * environment enables it at mslam_create.  Ignored while per-kernel profiling is on. */
+int mslam_set_graphs(mslam_ctx* ctx, int enable);
+
 /* ---- R1-R6: ORB detect + describe --------------------------------------------------
  * Stands in for `detector.detect(frameBuffer, keypoints)` + `extractor.compute(
  * frameBuffer, keypoints, descriptor)` of FeatureExtractor::process

@@ -180,6 +180,10 @@ class Context:
         return float(ms.value)
 
     # ---- per-kernel HIP-event timing
+    def set_graphs(self, enable: bool = True):
+        """Replay the extract chain as a captured HIP graph (launch-bound small batches)."""
+        self._check(lib().mslam_set_graphs(self._h, int(bool(enable))), "mslam_set_graphs")
+
     def profile_enable(self, max_launches: int):
         self._check(lib().mslam_profile_enable(self._h, max_launches), "mslam_profile_enable")
 

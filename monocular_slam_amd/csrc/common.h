@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string>
+#include <unordered_map>
 #include <vector>
 #include "../../include/mslam.h"
 
@@ -39,7 +40,17 @@ struct mslam_ctx {
     void* stage = nullptr;
     size_t stage_bytes = 0;
     Prof prof;
+    // optional replay of captured launch chains (mslam_set_graphs): key = hash of the call's arguments
+    bool graphs = false;
+    std::unordered_map<uint64_t, hipGraphExec_t> graph_cache;
 };
+
+// 1: the chain was replayed from the cache (nothing left to enqueue); 0: capture has begun -- enqueue, then ctx_graph_end;
+// -1: graphs are off (enqueue directly).  ctx_graph_end instantiates, caches and launches the captured chain.
+int ctx_graph_begin(mslam_ctx* ctx, uint64_t key);
+int ctx_graph_end(mslam_ctx* ctx, uint64_t key);
+void ctx_graph_clear(mslam_ctx* ctx);
+uint64_t ctx_hash(const void* data, size_t n, uint64_t seed);
 
 // returns the pair index or -1 (profiling off / pool exhausted)
 int prof_begin(mslam_ctx* ctx, int kid);

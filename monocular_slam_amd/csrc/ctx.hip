@@ -1,5 +1,6 @@
 // ctx.hip -- context, memory and timing helpers of the C ABI (include/mslam.h).
 #include "common.h"
+#include <cstdlib>
 #include <cstring>
 
 const char* const kKernelNames[K_COUNT] = {
@@ -21,6 +22,48 @@ int prof_begin(mslam_ctx* ctx, int kid)
 void prof_end(mslam_ctx* ctx, int pair)
 {
     if (pair >= 0) (void)hipEventRecord(ctx->prof.ev[2 * pair + 1], ctx->stream);
+}
+
+uint64_t ctx_hash(const void* data, size_t n, uint64_t h)
+{
+    const unsigned char* p = static_cast<const unsigned char*>(data); // FNV-1a
+    for (size_t i = 0; i < n; i++) { h ^= p[i]; h *= 1099511628211ull; }
+    return h;
+}
+
+void ctx_graph_clear(mslam_ctx* ctx)
+{
+    for (auto& kv : ctx->graph_cache) (void)hipGraphExecDestroy(kv.second);
+    ctx->graph_cache.clear();
+}
+
+int ctx_graph_begin(mslam_ctx* ctx, uint64_t key)
+{
+    if (!ctx->graphs || ctx->prof.on) return -1;
+    auto it = ctx->graph_cache.find(key);
+    if (it != ctx->graph_cache.end()) {
+        if (hipGraphLaunch(it->second, ctx->stream) == hipSuccess) return 1;
+        (void)hipGetLastError();
+        (void)hipGraphExecDestroy(it->second);
+        ctx->graph_cache.erase(it);
+        return -1;
+    }
+    if (ctx->graph_cache.size() >= 64) ctx_graph_clear(ctx); // callers cycle through a handful of argument sets
+    if (hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    return 0;
+}
+
+int ctx_graph_end(mslam_ctx* ctx, uint64_t key)
+{
+    hipGraph_t graph = nullptr;
+    HIP_TRY(ctx, hipStreamEndCapture(ctx->stream, &graph));
+    hipGraphExec_t exec = nullptr;
+    hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    HIP_TRY(ctx, e);
+    ctx->graph_cache[key] = exec;
+    HIP_TRY(ctx, hipGraphLaunch(exec, ctx->stream));
+    return MSLAM_OK;
 }
 
 extern "C" {
@@ -59,7 +102,17 @@ int mslam_create(mslam_ctx** out, int device, int max_w, int max_h, int max_kpts
         delete ctx;
         return MSLAM_ERR_HIP;
     }
+    if (const char* g = std::getenv("MSLAM_GRAPHS")) ctx->graphs = std::atoi(g) != 0;
     *out = ctx;
+    return MSLAM_OK;
+}
+
+int mslam_set_graphs(mslam_ctx* ctx, int enable)
+{
+    if (!ctx) return MSLAM_ERR_INVALID;
+    MSLAM_TRY(ctx_set_device(ctx));
+    if (!enable) { HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); ctx_graph_clear(ctx); }
+    ctx->graphs = enable != 0;
     return MSLAM_OK;
 }
 
@@ -68,6 +121,7 @@ void mslam_destroy(mslam_ctx* ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    ctx_graph_clear(ctx);
     orb_plan_destroy(ctx);
     for (hipEvent_t e : ctx->prof.ev) (void)hipEventDestroy(e);
     if (ctx->scratch) (void)hipFree(ctx->scratch);

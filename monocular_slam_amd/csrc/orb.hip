@@ -794,6 +794,7 @@ struct OrbPlan {
 void orb_plan_destroy(mslam_ctx* ctx)
 {
     if (!ctx->orb) return;
+    ctx_graph_clear(ctx); // captured chains point into the plan's arena
     if (ctx->orb->arena) (void)hipFree(ctx->orb->arena);
     delete ctx->orb;
     ctx->orb = nullptr;
@@ -959,11 +960,18 @@ int mslam_orb_extract_batch_dev(mslam_ctx* ctx, const uint8_t* imgs, int B, int 
         od.lv[0].frame_stride = frame_stride;
     } else {
         od.lv[0].img = pl->level0; od.lv[0].pitch = pl->level0_pitch; od.lv[0].frame_stride = pl->level0_fstride;
-        LAUNCH(ctx, K_GRAY, bgr2gray_k, dim3((w + 255) / 256, h, B), dim3(256), 0, imgs, w, h, stride,
-                           (long long)frame_stride, channels, od.lv[0].img, od.lv[0].pitch, od.lv[0].frame_stride);
     }
     pl->last_l0 = od.lv[0].img; pl->last_l0_pitch = od.lv[0].pitch;
-    HIP_TRY(ctx, hipMemsetAsync(pl->counters, 0, pl->counters_bytes, st));
+    // optional graph replay: the whole chain below depends only on these values
+    struct { const void* imgs; const void* kps; const void* desc; const void* n_out; const void* status; const void* plan;
+             int64_t fstride; int B, w, h, stride, channels, cap; } key_src = { imgs, kps, desc, n_out, status_dev, pl, frame_stride, B, w, h, stride, channels, cap };
+    const uint64_t key = ctx_hash(&key_src, sizeof(key_src), 14695981039346656037ull);
+    const int g = ctx_graph_begin(ctx, key);
+    if (g == 1) return MSLAM_OK;
+    if (!alias)
+        LAUNCH(ctx, K_GRAY, bgr2gray_k, dim3((w + 255) / 256, h, B), dim3(256), 0, imgs, w, h, stride,
+                           (long long)frame_stride, channels, od.lv[0].img, od.lv[0].pitch, od.lv[0].frame_stride);
+    hipError_t me = hipMemsetAsync(pl->counters, 0, pl->counters_bytes, st);
     for (int l = 1; l < od.L; l++) {
         const LevelDesc& s = od.lv[l - 1];
         const LevelDesc& d = od.lv[l];
@@ -976,6 +984,8 @@ int mslam_orb_extract_batch_dev(mslam_ctx* ctx, const uint8_t* imgs, int B, int 
     DescArgs da{ kps, desc, n_out, status_dev, cap };
     const int max_total = cap < od.max_kpts * od.L ? cap : od.max_kpts * od.L;
     LAUNCH(ctx, K_DESCRIBE, describe_k, dim3((max_total + DESC_WAVES - 1) / DESC_WAVES + 1, B), dim3(64 * DESC_WAVES), 0, od, da);
+    if (g == 0) MSLAM_TRY(ctx_graph_end(ctx, key)); // ends the capture on every path; launch errors surface here
+    HIP_TRY(ctx, me);
     HIP_TRY(ctx, hipGetLastError());
     return MSLAM_OK;
 }

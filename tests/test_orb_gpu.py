@@ -144,3 +144,34 @@ def test_4k_frame_and_wide_scale_factors(oracle):
         ko, do = oracle.orb_extract(flat, _oracle_params(oracle, api.default_orb_params(1000)), cap=8192)
         assert 100 < len(ko)
         _same_keypoints(kg, dg, ko, do)
+
+
+def test_graph_replay_of_the_extract_chain(oracle):
+    """mslam_set_graphs: the captured chain replays with identical results, for several argument sets (double-buffered
+    outputs, new frame contents in the same buffers) and after the plan is rebuilt for another geometry."""
+    with api.Context(device=0, max_w=1280, max_h=720, max_kpts=2048, batch=2) as c:
+        c.set_graphs(True)
+        B, w, h, cap = 2, 640, 480, 1024
+        p = api.default_orb_params(500)
+        dimg = api.DevBuf(c, B * w * h)
+        outs = [(api.DevBuf(c, B * cap * 24), api.DevBuf(c, B * cap * 32), api.DevBuf(c, B * 4), api.DevBuf(c, B * 4)) for _ in range(2)]
+        for step in range(6):                      # steps 0/1 capture (two output sets), 2.. replay
+            frames = np.stack([synth.textured_frame(w, h, 700 + 10 * step + i) for i in range(B)])
+            dimg.upload(frames)
+            dk, dd, dn, ds = outs[step % 2]
+            c.orb_extract_batch_dev(dimg.ptr, B, w, h, w, w * h, 1, p, dk.ptr, dd.ptr, cap, dn.ptr, ds.ptr)
+            c.sync()
+            n = dn.download(np.int32, (B,))
+            kall, dall = dk.download(api.KP_DTYPE, (B, cap)), dd.download(np.uint8, (B, cap, 32))
+            for b in range(B):
+                ko, do = oracle.orb_extract(frames[b], _oracle_params(oracle, p), cap=8192)
+                _same_keypoints(kall[b, : n[b]], dall[b, : n[b]], ko, do)
+        # another geometry: the plan is rebuilt and the cached graphs are dropped
+        img = synth.textured_frame(800, 600, 3)
+        for _ in range(3):
+            kg, dg = c.orb_extract(img, api.default_orb_params(300))
+            ko, do = oracle.orb_extract(img, _oracle_params(oracle, api.default_orb_params(300)), cap=8192)
+            _same_keypoints(kg, dg, ko, do)
+        c.set_graphs(False)
+        kg, dg = c.orb_extract(img, api.default_orb_params(300))
+        _same_keypoints(kg, dg, ko, do)
