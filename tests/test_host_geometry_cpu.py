@@ -1,0 +1,124 @@
+"""CPU tests of the host-side geometry that stays C++ in the product (monocular_slam_amd/host/Geometry.cpp): Jacobi
+eigen-solver, 3x3 SVD, dense LDL^T, Rt <-> SE3Quat, SE3 exp, essential-matrix decomposition, pose concatenation as
+written in the reference, sample tables -- against numpy on random inputs (through the mslam_geometry_check hook)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from monocular_slam_amd import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CHECK = os.path.join(ROOT, "monocular_slam_amd", "host", "mslam_geometry_check")
+
+
+def run(lines):
+    r = subprocess.run([CHECK], input="\n".join(lines) + "\n", capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stderr
+    return [np.array(l.split(), float) for l in r.stdout.strip().splitlines()]
+
+
+def fmt(*arrs):
+    return " ".join(repr(float(v)) for a in arrs for v in np.asarray(a, float).ravel())
+
+
+def test_jacobi_svd_ldlt():
+    rng = np.random.default_rng(0)
+    lines, refs = [], []
+    for n in (3, 6, 9, 12):
+        A = rng.normal(size=(n, n)); A = A + A.T
+        lines.append(f"jacobi {n} " + fmt(A)); refs.append(("jacobi", A))
+    for k in range(6):
+        A = rng.normal(size=(3, 3))
+        if k == 4:
+            A[:, 2] = A[:, 0] + A[:, 1]          # rank 2
+        if k == 5:
+            A = np.outer(rng.normal(size=3), rng.normal(size=3))  # rank 1
+        lines.append("svd3 " + fmt(A)); refs.append(("svd3", A))
+    for n in (1, 6, 30, 54):
+        M = rng.normal(size=(n, n)); S = M @ M.T + n * np.eye(n); b = rng.normal(size=n)
+        lines.append(f"ldlt {n} " + fmt(S, b)); refs.append(("ldlt", (S, b)))
+    lines.append("ldlt 2 " + fmt(np.zeros((2, 2)), np.ones(2))); refs.append(("ldlt0", None))
+    for out, (kind, ref) in zip(run(lines), refs):
+        if kind == "jacobi":
+            n = ref.shape[0]
+            w, V = out[:n], out[n:].reshape(n, n)
+            np.testing.assert_allclose(w, np.linalg.eigvalsh(ref), rtol=1e-12, atol=1e-12)
+            np.testing.assert_allclose(V.T @ V, np.eye(n), atol=1e-12)
+            np.testing.assert_allclose(ref @ V, V * w, atol=1e-11)
+        elif kind == "svd3":
+            U, s, Vt = out[:9].reshape(3, 3), out[9:12], out[12:].reshape(3, 3)
+            # singular values come from the eigenvalues of A^T A: absolute accuracy ~ sqrt(eps) * s_max
+            np.testing.assert_allclose(s, np.linalg.svd(ref, compute_uv=False), rtol=1e-9, atol=1e-7 * np.abs(ref).max())
+            np.testing.assert_allclose(U @ np.diag(s) @ Vt, ref, atol=1e-7 * np.abs(ref).max())
+            np.testing.assert_allclose(U.T @ U, np.eye(3), atol=1e-11)       # also for rank-deficient input
+            np.testing.assert_allclose(Vt @ Vt.T, np.eye(3), atol=1e-11)
+        elif kind == "ldlt":
+            S, b = ref
+            assert out[0] == 1
+            np.testing.assert_allclose(out[1:], np.linalg.solve(S, b), rtol=1e-9, atol=1e-12)
+        else:
+            assert out[0] == 0                                               # zero pivot is reported
+
+
+def test_pose_conversions_and_essential_matrix():
+    rng = np.random.default_rng(1)
+    lines, refs = [], []
+    for _ in range(8):
+        R = synth.rodrigues(rng.normal(size=3) * rng.uniform(0.01, 3.0)); t = rng.normal(size=3)
+        Rt = np.c_[R, t]
+        lines.append("rtquat " + fmt(Rt)); refs.append(("rtquat", Rt))
+        tx = np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]])
+        lines.append("extract " + fmt(tx @ R)); refs.append(("extract", (R, t)))
+        Rt2 = np.c_[synth.rodrigues(rng.normal(size=3)), rng.normal(size=3)]
+        lines.append("concat " + fmt(Rt, Rt2)); refs.append(("concat", (Rt, Rt2)))
+        d = np.r_[rng.normal(size=3) * 0.3, rng.normal(size=3)]
+        q = synth.quat_from_R(R)
+        lines.append("se3exp " + fmt(d, np.r_[t, q])); refs.append(("se3exp", (d, R, t)))
+    lines.append("se3exp " + fmt(np.r_[np.zeros(3), [0.1, -0.2, 0.3]], np.r_[np.zeros(3), [0, 0, 0, 1]])); refs.append(("se3exp0", None))
+    for out, (kind, ref) in zip(run(lines), refs):
+        if kind == "rtquat":
+            p, back = out[:7], out[7:].reshape(3, 4)
+            np.testing.assert_allclose(back, ref, atol=1e-12)
+            assert abs(np.linalg.norm(p[3:]) - 1) < 1e-12 and p[6] >= 0
+            np.testing.assert_allclose(p[:3], ref[:, 3], atol=0)
+        elif kind == "extract":
+            R, t = ref
+            Rs, ts = [out[:9].reshape(3, 3), out[9:18].reshape(3, 3)], [out[18:21], out[21:24]]
+            for Rc in Rs:
+                np.testing.assert_allclose(Rc.T @ Rc, np.eye(3), atol=1e-9)
+                assert np.linalg.det(Rc) > 0
+            assert min(np.abs(Rc - R).max() for Rc in Rs) < 1e-9                       # the true rotation is a candidate
+            tn = t / np.linalg.norm(t)
+            np.testing.assert_allclose(ts[0], -ts[1], atol=1e-12)
+            assert min(np.abs(ts[0] - tn).max(), np.abs(ts[1] - tn).max()) < 1e-9      # and +-t/|t|
+        elif kind == "concat":
+            A, B = ref
+            # as written in the reference (src/CameraPoseEstimator.cpp:248-255): both operands are padded with a ZERO fourth
+            # row, so the result is [R1 R2 | R1 t2] -- t1 never enters (the reference only calls it with the identity first)
+            np.testing.assert_allclose(out.reshape(3, 4), np.c_[A[:, :3] @ B[:, :3], A[:, :3] @ B[:, 3]], atol=1e-12)
+        elif kind == "se3exp":
+            d, R, t = ref
+            om, up = d[:3], d[3:]
+            th = np.linalg.norm(om)
+            Om = np.array([[0, -om[2], om[1]], [om[2], 0, -om[0]], [-om[1], om[0], 0]])
+            Re = np.eye(3) + np.sin(th) / th * Om + (1 - np.cos(th)) / th ** 2 * Om @ Om
+            V = np.eye(3) + (1 - np.cos(th)) / th ** 2 * Om + (th - np.sin(th)) / th ** 3 * Om @ Om
+            Rn, tn = Re @ R, Re @ t + V @ up
+            qn = synth.quat_from_R(Rn)
+            np.testing.assert_allclose(out[:3], tn, atol=1e-11)
+            assert min(np.abs(out[3:] - qn).max(), np.abs(out[3:] + qn).max()) < 1e-11
+        else:
+            np.testing.assert_allclose(out, [0.1, -0.2, 0.3, 0, 0, 0, 1], atol=1e-15)      # pure translation
+
+
+def test_sample_tables_are_distinct_and_reproducible():
+    a, b, c = run(["table 50 200 8 77", "table 50 200 8 77", "table 50 200 8 78"])
+    np.testing.assert_array_equal(a, b)
+    assert (a != c).any()
+    T = a.reshape(200, 8).astype(int)
+    assert T.min() >= 0 and T.max() < 50
+    assert all(len(set(r)) == 8 for r in T)
+    (d,) = run(["table 8 5 8 3"])
+    assert all(sorted(r) == list(range(8)) for r in d.reshape(5, 8).astype(int))
