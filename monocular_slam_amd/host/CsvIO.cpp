@@ -153,3 +153,17 @@ void Util::saveMapPointsOnlyIdXYZ(const std::vector<MapPoint>& map_points, std::
     out.precision(17);
     for (const MapPoint& m : map_points) out << m.id << "," << m.worldPosition.x << "," << m.worldPosition.y << "," << m.worldPosition.z << "\n";
 }
+
+std::map<int, std::string> Util::loadFrameIdToImageFileName(std::string info_filename)
+{
+    std::map<int, std::string> frame_id_to_file;
+    std::ifstream in(info_filename);
+    std::string line;
+    while (std::getline(in, line)) {
+        std::istringstream is(line);
+        int id;
+        std::string name;
+        if (is >> id >> name) frame_id_to_file[id] = name;
+    }
+    return frame_id_to_file;
+}

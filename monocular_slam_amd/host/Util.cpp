@@ -112,6 +112,32 @@ void Util::LocalBundleAdjustment(DataManager& data, int first_free_frame_id, int
           (double)THRESH_HUBER_FULL_BA, true);
 }
 
+cv::Mat Util::ComputeF(Frame f1, Frame f2)
+{
+    if (f1.Rt.empty() || f2.Rt.empty() || f1.K.empty() || f2.K.empty()) return cv::Mat();
+    double R1[9], R2[9], t1[3], t2[3], K1[9], K2[9];
+    for (int i = 0; i < 3; i++) {
+        for (int j = 0; j < 3; j++) { R1[i * 3 + j] = f1.Rt.at<double>(i, j); R2[i * 3 + j] = f2.Rt.at<double>(i, j);
+                                      K1[i * 3 + j] = f1.K.at<double>(i, j); K2[i * 3 + j] = f2.K.at<double>(i, j); }
+        t1[i] = f1.Rt.at<double>(i, 3); t2[i] = f2.Rt.at<double>(i, 3);
+    }
+    // X2 = R X1 + t with R = R2 R1^T, t = t2 - R t1
+    double R[9], t[3];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) { double s = 0; for (int k = 0; k < 3; k++) s += R2[i * 3 + k] * R1[j * 3 + k]; R[i * 3 + j] = s; }
+    for (int i = 0; i < 3; i++) t[i] = t2[i] - (R[i * 3] * t1[0] + R[i * 3 + 1] * t1[1] + R[i * 3 + 2] * t1[2]);
+    const double tx[9] = { 0, -t[2], t[1], t[2], 0, -t[0], -t[1], t[0], 0 };
+    double E[9], K1i[9], K2i[9], T[9], F[9];
+    geom::matmul3(tx, R, E);
+    if (!geom::inv3(K1, K1i) || !geom::inv3(K2, K2i)) return cv::Mat();
+    geom::matmul3(E, K1i, T);
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) { double s = 0; for (int k = 0; k < 3; k++) s += K2i[k * 3 + i] * T[k * 3 + j]; F[i * 3 + j] = s; } // K2^-T * T
+    cv::Mat out(3, 3, cv::CV_64F);
+    for (int i = 0; i < 9; i++) out.at<double>(i / 3, i % 3) = F[i];
+    return out;
+}
+
 bool Util::poseBARoundsEnabled = false;
 std::vector<uint8_t> Util::lastPoseBAOutliers;
 

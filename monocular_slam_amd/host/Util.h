@@ -2,6 +2,8 @@
 // spelling "GlobalBundleAdjustemnt"), same defaults.  The g2o graph + Levenberg-Marquardt of src/Util.cpp:34-220 is
 // replaced by: linearisation on the GPU (mslam_ba_plan_*), LM control + Schur complement + LDL^T on the host.
 #pragma once
+#include <map>
+#include <string>
 #include "DataManager.h"
 
 class Util {
@@ -23,6 +25,9 @@ public:
     static bool poseBARoundsEnabled;
     // per edge of the last PoseBundleAdjustment call: 1 = classified outlier (all 1 if the rounds did not run)
     static std::vector<uint8_t> lastPoseBAOutliers;
+    // Fundamental matrix implied by two posed frames, x2^T F x1 = 0 with F = K2^-T [t]x R K1^-1, (R, t) = pose 2 relative to
+    // pose 1; 3x3 CV_64F, empty if a pose or K is missing.  (The reference declares it and returns an empty Mat, src/Util.cpp:24-26.)
+    static cv::Mat ComputeF(Frame f1, Frame f2);
     static Frame* findFrameById(std::vector<Frame>& frames, int target_id);
     static MapPoint* findMapPointById(std::vector<MapPoint>& map_points, int target_id);
     // CSV fixtures in the reference's formats (src/Util.cpp:384-588) and the matching writers (the reference has none)
@@ -30,6 +35,8 @@ public:
     static std::vector<MapPoint> loadMapPoints(std::string map_points_filename);
     static std::vector<Frame> loadFramesOnlyIdRt(std::string frame_filename);
     static std::vector<MapPoint> loadMapPointsOnlyIdXYZ(std::string map_points_filename);
+    // "<frame id> <image file name>" per line (src/Util.cpp:590-612; UnitTest/compareORBSLAM reads out_info.txt with it)
+    static std::map<int, std::string> loadFrameIdToImageFileName(std::string info_filename);
     static void saveFrames(const std::vector<Frame>& frames, std::string frame_filename);
     static void saveMapPoints(const std::vector<MapPoint>& map_points, std::string map_points_filename);
     static void saveFramesOnlyIdRt(const std::vector<Frame>& frames, std::string frame_filename);

@@ -122,3 +122,30 @@ def test_sample_tables_are_distinct_and_reproducible():
     assert all(len(set(r)) == 8 for r in T)
     (d,) = run(["table 8 5 8 3"])
     assert all(sorted(r) == list(range(8)) for r in d.reshape(5, 8).astype(int))
+
+
+def test_util_computef_and_frame_id_table(tmp_path):
+    """Util::ComputeF (a stub in the reference, src/Util.cpp:24-26; here the F implied by two posed frames) and
+    Util::loadFrameIdToImageFileName (src/Util.cpp:590-612) through a CPU-only hook."""
+    util = os.path.join(ROOT, "monocular_slam_amd", "host", "mslam_util_check")
+    rng = np.random.default_rng(4)
+    K = synth.K_TUM1
+    poses = [np.c_[synth.rodrigues(rng.normal(size=3) * 0.2), rng.normal(size=3)] for _ in range(3)]
+    with open(tmp_path / "Frames.csv", "w") as f:
+        for i, Rt in enumerate(poses):
+            f.write(",".join([str(i + 5)] + [repr(float(v)) for v in Rt[:, :3].ravel()] + [repr(float(v)) for v in Rt[:, 3]]) + "\n")
+    r = subprocess.run([util, "computef", str(tmp_path / "Frames.csv"), *[repr(float(v)) for v in (K[0, 0], K[1, 1], K[0, 2], K[1, 2])], "5", "7"],
+                       capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stderr
+    F = np.array(r.stdout.split()[1:], float).reshape(3, 3)
+    X = rng.uniform(-2, 2, (40, 3)) + np.array([0, 0, 8.0])
+    def proj(Rt):
+        Xc = X @ Rt[:, :3].T + Rt[:, 3]
+        return np.c_[K[0, 0] * Xc[:, 0] / Xc[:, 2] + K[0, 2], K[1, 1] * Xc[:, 1] / Xc[:, 2] + K[1, 2], np.ones(len(X))]
+    x1, x2 = proj(poses[0]), proj(poses[2])
+    resid = np.einsum("ni,ij,nj->n", x2, F, x1)
+    assert np.abs(resid).max() < 1e-9 * np.abs(F).max() * 1e6       # x2^T F x1 = 0 for every scene point
+    assert abs(np.linalg.det(F)) < 1e-12 * np.abs(F).max() ** 3      # rank 2
+    (tmp_path / "out_info.txt").write_text("3 1305031102.175304.png\n\n11 rgb/1305031102.211214.png\n4 a.png\n")
+    r = subprocess.run([util, "info", str(tmp_path / "out_info.txt")], capture_output=True, text=True, timeout=60)
+    assert r.stdout.split("\n")[:3] == ["3 1305031102.175304.png", "4 a.png", "11 rgb/1305031102.211214.png"]
