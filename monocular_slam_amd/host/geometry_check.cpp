@@ -8,11 +8,14 @@
 //   extract E[9]                -> R0[9] R1[9] t0[3] t1[3]
 //   concat Rt1[12] Rt2[12]      -> Rt[12]
 //   table n H k seed            -> H*k indices
+//   hls m n A[m*n]              -> x[n]   (solveHLS; then dehomogenize when n == 4)
+//   conv Rt[12]                 -> Converter::cvMatToSE3Quat -> SE3QuatToCvMat round trip (12 values)
 #include <cstdio>
 #include <iostream>
 #include <string>
 #include <vector>
 #include "Geometry.h"
+#include "HostMath.h"
 
 static void out(const double* v, int n) { for (int i = 0; i < n; i++) std::printf(" %.17g", v[i]); }
 
@@ -63,6 +66,18 @@ int main()
         } else if (cmd == "table") {
             int n, H, k; unsigned long long seed; std::cin >> n >> H >> k >> seed;
             for (int32_t v : geom::sampleTable(n, H, k, seed)) std::printf(" %d", v);
+        } else if (cmd == "hls") {
+            int m, n; std::cin >> m >> n;
+            cv::Mat A(m, n, cv::CV_64F), x;
+            for (int i = 0; i < m * n; i++) std::cin >> A.at<double>(i / n, i % n);
+            solveHLS(A, x);
+            if (n == 4) dehomogenize(x);
+            out(x.ptr<double>(0), n);
+        } else if (cmd == "conv") {
+            cv::Mat Rt(3, 4, cv::CV_64F);
+            for (int i = 0; i < 12; i++) std::cin >> Rt.at<double>(i / 4, i % 4);
+            cv::Mat back = Converter::SE3QuatToCvMat(Converter::cvMatToSE3Quat(Rt));
+            out(back.ptr<double>(0), 12);
         } else return 2;
         std::printf("\n");
     }

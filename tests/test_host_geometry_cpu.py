@@ -149,3 +149,14 @@ def test_util_computef_and_frame_id_table(tmp_path):
     (tmp_path / "out_info.txt").write_text("3 1305031102.175304.png\n\n11 rgb/1305031102.211214.png\n4 a.png\n")
     r = subprocess.run([util, "info", str(tmp_path / "out_info.txt")], capture_output=True, text=True, timeout=60)
     assert r.stdout.split("\n")[:3] == ["3 1305031102.175304.png", "4 a.png", "11 rgb/1305031102.211214.png"]
+
+
+def test_reference_named_helpers():
+    """host/HostMath.h: solveHLS / dehomogenize (src/CommonMath.cpp:17-27) and the Converter round trip (src/Converter.cpp:8-31)."""
+    rng = np.random.default_rng(6)
+    Xh = np.array([0.3, -1.2, 4.0, 1.0])
+    A = rng.normal(size=(6, 4)); A -= np.outer(A @ Xh, Xh) / (Xh @ Xh)        # rows orthogonal to Xh: null vector = Xh
+    Rt = np.c_[synth.rodrigues(rng.normal(size=3)), rng.normal(size=3)]
+    x, back = run(["hls 6 4 " + fmt(A), "conv " + fmt(Rt)])
+    np.testing.assert_allclose(x, Xh, atol=1e-9)
+    np.testing.assert_allclose(back.reshape(3, 4), Rt, atol=1e-12)
