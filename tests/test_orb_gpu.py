@@ -175,3 +175,26 @@ def test_graph_replay_of_the_extract_chain(oracle):
         c.set_graphs(False)
         kg, dg = c.orb_extract(img, api.default_orb_params(300))
         _same_keypoints(kg, dg, ko, do)
+
+
+def test_unsupported_parameters_and_sizes_are_errors(ctx):
+    """Parameters outside the restated ORB (WTA_K != 2, patch size != 31, first level != 0, ...) and frames beyond the
+    context's capacity are refused with a status, never computed approximately."""
+    img = synth.textured_frame(320, 240, 3)
+    for kw in (dict(wta_k=3), dict(patch_size=25), dict(first_level=1), dict(nlevels=0), dict(nlevels=17), dict(scale_factor=1.0),
+               dict(edge_threshold=10), dict(fast_threshold=0), dict(score_type=2), dict(nfeatures=-1)):
+        p = api.default_orb_params(300)
+        for k, v in kw.items():
+            setattr(p, k, v)
+        with pytest.raises(api.MslamError) as e:
+            ctx.orb_extract(img, p)
+        assert e.value.status == api.ERR_INVALID, kw
+    big = np.zeros((1081, 1920), np.uint8)
+    with pytest.raises(api.MslamError) as e:
+        ctx.orb_extract(big, api.default_orb_params(300))
+    assert e.value.status == api.ERR_CAPACITY
+    with pytest.raises(api.MslamError) as e:                       # too small for the 16 x 16 minimum
+        ctx.orb_extract(np.zeros((12, 12), np.uint8), api.default_orb_params(300))
+    assert e.value.status == api.ERR_INVALID
+    kg, dg = ctx.orb_extract(img, api.default_orb_params(300))     # the context is still usable afterwards
+    assert len(kg) > 50
