@@ -65,6 +65,17 @@ int mslam_dev_alloc(mslam_ctx* ctx, void** dptr, uint64_t bytes);
 int mslam_dev_free(mslam_ctx* ctx, void* dptr);
 int mslam_memcpy_h2d(mslam_ctx* ctx, void* dst_dev, const void* src_host, uint64_t bytes);
 int mslam_memcpy_d2h(mslam_ctx* ctx, void* dst_host, const void* src_dev, uint64_t bytes);
+/* Asynchronous forms: enqueued on the context's stream, no host sync (use pinned host memory from mslam_host_alloc for
+ * real overlap).  Frame ingest uses them on a second context (= copy stream) with mslam_event_record on that context
+ * and mslam_stream_wait_event on the compute context, so that the H2D of frame i+1 overlaps the kernels of frame i
+ * (the reference loads frames from disk before the loop, src/main.cpp:35-37; a live camera would be this path). */
+int mslam_memcpy_h2d_async(mslam_ctx* ctx, void* dst_dev, const void* src_host, uint64_t bytes);
+int mslam_memcpy_d2h_async(mslam_ctx* ctx, void* dst_host, const void* src_dev, uint64_t bytes);
+int mslam_memcpy_d2d_async(mslam_ctx* ctx, void* dst_dev, const void* src_dev, uint64_t bytes);
+int mslam_host_alloc(mslam_ctx* ctx, void** hptr, uint64_t bytes);   /* pinned (page-locked) host memory */
+int mslam_host_free(mslam_ctx* ctx, void* hptr);
+/* make this context's stream wait for an event recorded (mslam_event_record) on another context of the same device */
+int mslam_stream_wait_event(mslam_ctx* ctx, void* ev);
 
 /* HIP-event timing on the context's stream (so FFI callers can bracket launches) */
 int mslam_event_create(mslam_ctx* ctx, void** ev);
@@ -330,11 +341,31 @@ int mslam_ba_plan_get_state(mslam_ba_plan* plan, double* poses_host, double* poi
 
 /* ---- multi-GPU -------------------------------------------------------------------------
  * The path shards by independent streams (one process per GPU, no data-path collective).
- * The only exchange is the optional sharding of ONE problem's hypotheses over ranks:
- * every rank scores its slice and the int32 inlier counts are all-gathered (RCCL, by
- * the host side through torch.distributed); the global winner is then
- * mslam_argmax_counts over the gathered vector (max count, lowest index on ties). */
+ * The only exchange is the optional sharding of ONE problem's hypotheses over ranks (the
+ * solvePnPRansac / findFundamentalMat call sites, src/CameraPoseEstimator.cpp:472,563):
+ * every rank scores its slice and the int32 inlier counts are all-gathered over RCCL
+ * (xGMI inside a node; <= 16 KiB, latency-bound); the global winner is then
+ * mslam_argmax_counts over the gathered vector (max count, lowest index on ties).
+ * The reference has no counterpart (single process). */
 int mslam_argmax_counts(const int32_t* counts, int n, int* best, int* best_count);
+
+/* One process per GPU.  Rank 0 obtains the 128-byte id and the host side hands it to the other ranks (file, socket,
+ * MPI, torch.distributed store ...); every rank then creates its communicator on its own context.  RCCL is bound
+ * lazily (dlopen librccl.so.1): MSLAM_ERR_NO_DEVICE if it cannot be loaded, MSLAM_ERR_HIP (+ mslam_last_hip_error) if
+ * an RCCL call fails. */
+#define MSLAM_COMM_ID_BYTES 128
+typedef struct mslam_comm mslam_comm;
+int mslam_comm_unique_id(uint8_t id[MSLAM_COMM_ID_BYTES]);
+int mslam_comm_create(mslam_ctx* ctx, const uint8_t id[MSLAM_COMM_ID_BYTES], int rank, int nranks, mslam_comm** out);
+int mslam_comm_info(mslam_comm* comm, int* rank, int* nranks, int* rccl_version);
+/* recv[r*n .. r*n+n) = rank r's send.  _dev: device pointers, enqueued on the context's stream (ordered behind the
+ * scoring kernels, no host sync); the un-suffixed form takes host pointers and synchronises. */
+int mslam_comm_allgather_i32_dev(mslam_comm* comm, const int32_t* send_dev, int n, int32_t* recv_dev);
+int mslam_comm_allgather_i32(mslam_comm* comm, const int32_t* send_host, int n, int32_t* recv_host);
+int mslam_comm_destroy(mslam_comm* comm);
+/* One process driving ngpu contexts on distinct devices: rank g contributes send + g*n (host);
+ * recv (host, ngpu*n) receives the gathered vector.  Communicators are created on first use per device list. */
+int mslam_allgather_i32(mslam_ctx* const* ctxs, int ngpu, const int32_t* send, int n, int32_t* recv);
 
 #ifdef __cplusplus
 }

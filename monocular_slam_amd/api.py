@@ -174,6 +174,19 @@ class Context:
     def record(self, e):
         self._check(lib().mslam_event_record(self._h, e), "mslam_event_record")
 
+    def wait_event(self, e):
+        """This context's stream waits for event `e` (recorded on another context of the same device)."""
+        self._check(lib().mslam_stream_wait_event(self._h, e), "mslam_stream_wait_event")
+
+    def memcpy_h2d_async(self, dst_ptr: int, src_ptr: int, nbytes: int):
+        self._check(lib().mslam_memcpy_h2d_async(self._h, vp(dst_ptr), vp(src_ptr), C.c_uint64(nbytes)), "mslam_memcpy_h2d_async")
+
+    def memcpy_d2h_async(self, dst_ptr: int, src_ptr: int, nbytes: int):
+        self._check(lib().mslam_memcpy_d2h_async(self._h, vp(dst_ptr), vp(src_ptr), C.c_uint64(nbytes)), "mslam_memcpy_d2h_async")
+
+    def memcpy_d2d_async(self, dst_ptr: int, src_ptr: int, nbytes: int):
+        self._check(lib().mslam_memcpy_d2d_async(self._h, vp(dst_ptr), vp(src_ptr), C.c_uint64(nbytes)), "mslam_memcpy_d2d_async")
+
     def elapsed_ms(self, a, b) -> float:
         ms = C.c_float(0)
         self._check(lib().mslam_event_elapsed_ms(self._h, a, b, C.byref(ms)), "mslam_event_elapsed_ms")
@@ -470,6 +483,108 @@ class DevBuf:
             self.free()
         except Exception:
             pass
+
+
+class PinnedBuf:
+    """Page-locked host memory (mslam_host_alloc) viewed as a numpy array; source/target of the async copies."""
+
+    def __init__(self, ctx: Context, shape, dtype=np.uint8):
+        self.ctx = ctx
+        self.shape, self.dtype = tuple(shape), np.dtype(dtype)
+        self.nbytes = int(np.prod(self.shape)) * self.dtype.itemsize
+        self._p = vp()
+        ctx._check(lib().mslam_host_alloc(ctx.handle, C.byref(self._p), C.c_uint64(max(1, self.nbytes))), "mslam_host_alloc")
+        buf = (C.c_uint8 * max(1, self.nbytes)).from_address(self._p.value)
+        self.array = np.frombuffer(buf, dtype=self.dtype, count=int(np.prod(self.shape))).reshape(self.shape)
+        ctx._adopt(self)
+
+    @property
+    def ptr(self) -> int:
+        return int(self._p.value or 0)
+
+    def free(self):
+        if self._p and self._p.value and self.ctx.handle:
+            self.array = None
+            lib().mslam_host_free(self.ctx.handle, self._p)
+            self._p = vp()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Comm:
+    """One rank of the RCCL communicator behind mslam_comm_* (one process per GPU)."""
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = (C.c_uint8 * 128)()
+        rc = lib().mslam_comm_unique_id(buf)
+        if rc != OK:
+            raise MslamError(rc, "mslam_comm_unique_id", lib().mslam_strerror(rc).decode())
+        return bytes(buf)
+
+    def __init__(self, ctx: Context, uid: bytes, rank: int, nranks: int):
+        assert len(uid) == 128
+        self.ctx, self.rank, self.nranks = ctx, rank, nranks
+        self._h = vp()
+        buf = (C.c_uint8 * 128).from_buffer_copy(uid)
+        ctx._check(lib().mslam_comm_create(ctx.handle, buf, rank, nranks, C.byref(self._h)), "mslam_comm_create")
+        ctx._adopt(self)
+
+    def info(self) -> dict:
+        r, n, v = C.c_int(0), C.c_int(0), C.c_int(0)
+        self.ctx._check(lib().mslam_comm_info(self._h, C.byref(r), C.byref(n), C.byref(v)), "mslam_comm_info")
+        return dict(rank=r.value, nranks=n.value, rccl_version=v.value)
+
+    def allgather_i32_dev(self, send_ptr: int, n: int, recv_ptr: int):
+        self.ctx._check(lib().mslam_comm_allgather_i32_dev(self._h, vp(send_ptr), n, vp(recv_ptr)), "mslam_comm_allgather_i32_dev")
+
+    def allgather_i32(self, send: np.ndarray) -> np.ndarray:
+        send = np.ascontiguousarray(send, np.int32)
+        recv = np.zeros(self.nranks * send.size, np.int32)
+        self.ctx._check(lib().mslam_comm_allgather_i32(self._h, _p(send, i32p), int(send.size), _p(recv, i32p)), "mslam_comm_allgather_i32")
+        return recv
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            lib().mslam_comm_destroy(self._h)
+            self._h = vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def allgather_i32_single_process(ctxs, send: np.ndarray) -> np.ndarray:
+    """mslam_allgather_i32: one process, len(ctxs) GPUs; send is (ngpu, n)."""
+    send = np.ascontiguousarray(send, np.int32)
+    ngpu, n = send.shape
+    arr = (vp * ngpu)(*[c.handle for c in ctxs])
+    recv = np.zeros(ngpu * n, np.int32)
+    rc = lib().mslam_allgather_i32(arr, ngpu, _p(send, i32p), n, _p(recv, i32p))
+    ctxs[0]._check(rc, "mslam_allgather_i32")
+    return recv
+
+
+def loaded_runtime_libs() -> dict:
+    """Which libamdhip64 / librccl files this process has mapped (two HIP runtimes in one process do not share memory)."""
+    out = {"libamdhip64": [], "librccl": []}
+    try:
+        for line in open("/proc/self/maps"):
+            if "r-xp" not in line:
+                continue
+            path = line.split()[-1]
+            for k in out:
+                if k in path and path not in out[k]:
+                    out[k].append(path)
+    except OSError:
+        pass
+    return out
 
 
 def ratio_filter(idx: np.ndarray, dist: np.ndarray, ratio: float):

@@ -623,6 +623,7 @@ int mslam_ba_plan_build_dev(mslam_ba_plan* pl)
 {
     if (!pl) return MSLAM_ERR_INVALID;
     mslam_ctx* ctx = pl->ctx;
+    MSLAM_TRY(ctx_set_device(ctx));
     const BaDev& d = pl->dev;
     hipStream_t st = ctx->stream;
     const int groups_per_block = BA_THREADS / GROUP;
@@ -644,6 +645,7 @@ int mslam_ba_plan_download(mslam_ba_plan* pl, mslam_ba_system* s)
 {
     if (!pl || !s) return MSLAM_ERR_INVALID;
     mslam_ctx* ctx = pl->ctx;
+    MSLAM_TRY(ctx_set_device(ctx));
     const BaDev& d = pl->dev;
     hipStream_t st = ctx->stream;
     auto dn = [&](void* dst, const void* src, size_t n) { return (dst && n) ? hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, st) : hipSuccess; };
@@ -667,6 +669,7 @@ int mslam_ba_plan_schur_dev(mslam_ba_plan* pl, double lambda)
     if (!pl) return MSLAM_ERR_INVALID;
     if (!pl->has_schur) return MSLAM_ERR_CAPACITY;
     mslam_ctx* ctx = pl->ctx;
+    MSLAM_TRY(ctx_set_device(ctx));
     BaDev d = pl->dev;
     d.lambda = lambda;
     pl->dev.lambda = lambda;
@@ -683,6 +686,7 @@ int mslam_ba_plan_download_schur(mslam_ba_plan* pl, double* S, double* bs)
 {
     if (!pl || !pl->has_schur) return MSLAM_ERR_INVALID;
     mslam_ctx* ctx = pl->ctx;
+    MSLAM_TRY(ctx_set_device(ctx));
     const BaDev& d = pl->dev;
     const size_t n6 = 6 * (size_t)d.n_free;
     if (S) HIP_TRY(ctx, hipMemcpyAsync(S, d.S, sizeof(double) * n6 * n6, hipMemcpyDeviceToHost, ctx->stream));
@@ -695,6 +699,7 @@ int mslam_ba_plan_backsub_dev(mslam_ba_plan* pl, const double* x_pose_host, int 
 {
     if (!pl || !pl->has_schur || !x_pose_host) return MSLAM_ERR_INVALID;
     mslam_ctx* ctx = pl->ctx;
+    MSLAM_TRY(ctx_set_device(ctx));
     const BaDev& d = pl->dev;
     HIP_TRY(ctx, hipMemcpyAsync(d.x, x_pose_host, sizeof(double) * 6 * d.n_free, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); // x_pose_host may be a temporary of the caller
@@ -709,6 +714,7 @@ int mslam_ba_plan_download_x(mslam_ba_plan* pl, double* x, double* scale_landmar
 {
     if (!pl || !pl->has_schur) return MSLAM_ERR_INVALID;
     mslam_ctx* ctx = pl->ctx;
+    MSLAM_TRY(ctx_set_device(ctx));
     const BaDev& d = pl->dev;
     if (x) HIP_TRY(ctx, hipMemcpyAsync(x, d.x, sizeof(double) * (6 * d.n_free + 3 * (size_t)d.n_points), hipMemcpyDeviceToHost, ctx->stream));
     if (scale_landmarks) HIP_TRY(ctx, hipMemcpyAsync(scale_landmarks, d.scale_l, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
@@ -720,6 +726,7 @@ int mslam_ba_plan_points_snapshot_dev(mslam_ba_plan* pl, int restore)
 {
     if (!pl || !pl->has_schur) return MSLAM_ERR_INVALID;
     mslam_ctx* ctx = pl->ctx;
+    MSLAM_TRY(ctx_set_device(ctx));
     const BaDev& d = pl->dev;
     const size_t n = sizeof(double) * 3 * (size_t)d.n_points;
     if (restore) HIP_TRY(ctx, hipMemcpyAsync(pl->d_points, d.points_bk, n, hipMemcpyDeviceToDevice, ctx->stream));
@@ -731,6 +738,7 @@ int mslam_ba_plan_get_state(mslam_ba_plan* pl, double* poses, double* points)
 {
     if (!pl) return MSLAM_ERR_INVALID;
     mslam_ctx* ctx = pl->ctx;
+    MSLAM_TRY(ctx_set_device(ctx));
     if (poses) HIP_TRY(ctx, hipMemcpyAsync(poses, pl->d_poses, sizeof(double) * 7 * pl->dev.n_poses, hipMemcpyDeviceToHost, ctx->stream));
     if (points) HIP_TRY(ctx, hipMemcpyAsync(points, pl->d_points, sizeof(double) * 3 * pl->dev.n_points, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));

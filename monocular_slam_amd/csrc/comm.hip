@@ -1,0 +1,207 @@
+// comm.hip -- the one collective of this path, at the C ABI: an int32 all-gather over RCCL (xGMI inside a node).
+//
+// The tracking path shards by independent streams (no data-path collective).  The only exchange is SURVEY.md 8e's
+// "secondary" split: the H hypotheses of ONE RANSAC problem (the solvePnPRansac call site, reference
+// src/CameraPoseEstimator.cpp:472) are scored H / nranks per GPU and the int32 inlier counts are all-gathered, after
+// which every rank takes the same argmax (mslam_argmax_counts).  Messages are <= 16 KiB: latency-bound, one RCCL
+// call per RANSAC, enqueued on the context's own stream so that it orders behind the scoring kernels without a host sync.
+//
+// RCCL is bound lazily (dlopen of librccl.so.1 on the first communicator): the single-GPU path never needs it and
+// must not fail to load where RCCL is absent.  Two forms:
+//   * one process per GPU (the deployment form): rank 0 calls mslam_comm_unique_id, the host side hands the 128 bytes
+//     to the other ranks by whatever channel it has (file, socket, MPI, torch.distributed store), every rank calls
+//     mslam_comm_create(ctx, id, rank, nranks).
+//   * one process, several GPUs: mslam_allgather_i32(ctxs, ngpu, ...) -- SURVEY.md 8b's literal signature; communicators
+//     are created once per distinct context list (ncclCommInitAll) and cached.
+#include "common.h"
+#include <rccl/rccl.h>
+#include <dlfcn.h>
+#include <cstring>
+#include <mutex>
+
+namespace {
+
+struct Rccl {
+    void* h = nullptr;
+    ncclResult_t (*GetVersion)(int*) = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    std::string err;
+};
+
+Rccl g_rccl;
+std::mutex g_rccl_mu;
+
+bool rccl_load()
+{
+    std::lock_guard<std::mutex> lk(g_rccl_mu);
+    if (g_rccl.h) return true;
+    const char* names[] = { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" };
+    void* h = nullptr;
+    for (const char* n : names) { h = dlopen(n, RTLD_NOW | RTLD_LOCAL); if (h) break; }
+    if (!h) { g_rccl.err = std::string("dlopen librccl: ") + (dlerror() ? dlerror() : "not found"); return false; }
+#define SYM(field, name) \
+    *reinterpret_cast<void**>(&g_rccl.field) = dlsym(h, name); \
+    if (!g_rccl.field) { g_rccl.err = std::string("dlsym ") + name; dlclose(h); return false; }
+    SYM(GetVersion, "ncclGetVersion") SYM(GetUniqueId, "ncclGetUniqueId") SYM(CommInitRank, "ncclCommInitRank")
+    SYM(CommInitAll, "ncclCommInitAll") SYM(CommDestroy, "ncclCommDestroy") SYM(AllGather, "ncclAllGather")
+    SYM(GroupStart, "ncclGroupStart") SYM(GroupEnd, "ncclGroupEnd") SYM(GetErrorString, "ncclGetErrorString")
+#undef SYM
+    g_rccl.h = h;
+    return true;
+}
+
+} // namespace
+
+struct mslam_comm {
+    mslam_ctx* ctx = nullptr;
+    ncclComm_t comm = nullptr;
+    int rank = 0, nranks = 1;
+    int32_t* stage = nullptr;   // device staging for the host-pointer form: [n] send + [n * nranks] recv
+    size_t stage_elems = 0;
+};
+
+#define RCCL_TRY(ctx, expr)                                                                                   \
+    do {                                                                                                      \
+        ncclResult_t _r = (expr);                                                                             \
+        if (_r != ncclSuccess) {                                                                              \
+            (ctx)->last_hip_error = std::string(#expr) + ": " + g_rccl.GetErrorString(_r);                    \
+            return MSLAM_ERR_HIP;                                                                             \
+        }                                                                                                     \
+    } while (0)
+
+// single-process multi-GPU communicators, keyed by the device list
+struct AllComm { std::vector<int> devs; std::vector<ncclComm_t> comms; };
+static std::vector<AllComm> g_all;
+
+extern "C" {
+
+int mslam_comm_unique_id(uint8_t id[MSLAM_COMM_ID_BYTES])
+{
+    if (!id) return MSLAM_ERR_INVALID;
+    static_assert(MSLAM_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "id size");
+    if (!rccl_load()) return MSLAM_ERR_NO_DEVICE;
+    ncclUniqueId u;
+    if (g_rccl.GetUniqueId(&u) != ncclSuccess) return MSLAM_ERR_HIP;
+    std::memcpy(id, u.internal, NCCL_UNIQUE_ID_BYTES);
+    return MSLAM_OK;
+}
+
+int mslam_comm_create(mslam_ctx* ctx, const uint8_t id[MSLAM_COMM_ID_BYTES], int rank, int nranks, mslam_comm** out)
+{
+    if (!ctx || !id || !out || nranks < 1 || rank < 0 || rank >= nranks) return MSLAM_ERR_INVALID;
+    if (!rccl_load()) { ctx->last_hip_error = g_rccl.err; return MSLAM_ERR_NO_DEVICE; }
+    MSLAM_TRY(ctx_set_device(ctx));
+    ncclUniqueId u;
+    std::memcpy(u.internal, id, NCCL_UNIQUE_ID_BYTES);
+    mslam_comm* c = new mslam_comm();
+    c->ctx = ctx; c->rank = rank; c->nranks = nranks;
+    ncclResult_t r = g_rccl.CommInitRank(&c->comm, nranks, u, rank);
+    if (r != ncclSuccess) {
+        ctx->last_hip_error = std::string("ncclCommInitRank: ") + g_rccl.GetErrorString(r);
+        delete c;
+        return MSLAM_ERR_HIP;
+    }
+    *out = c;
+    return MSLAM_OK;
+}
+
+int mslam_comm_info(mslam_comm* c, int* rank, int* nranks, int* rccl_version)
+{
+    if (!c) return MSLAM_ERR_INVALID;
+    if (rank) *rank = c->rank;
+    if (nranks) *nranks = c->nranks;
+    if (rccl_version) { int v = 0; (void)g_rccl.GetVersion(&v); *rccl_version = v; }
+    return MSLAM_OK;
+}
+
+int mslam_comm_allgather_i32_dev(mslam_comm* c, const int32_t* send_dev, int n, int32_t* recv_dev)
+{
+    if (!c || !send_dev || !recv_dev || n < 1) return MSLAM_ERR_INVALID;
+    MSLAM_TRY(ctx_set_device(c->ctx));
+    RCCL_TRY(c->ctx, g_rccl.AllGather(send_dev, recv_dev, (size_t)n, ncclInt32, c->comm, c->ctx->stream));
+    return MSLAM_OK;
+}
+
+int mslam_comm_allgather_i32(mslam_comm* c, const int32_t* send_host, int n, int32_t* recv_host)
+{
+    if (!c || !send_host || !recv_host || n < 1) return MSLAM_ERR_INVALID;
+    mslam_ctx* ctx = c->ctx;
+    MSLAM_TRY(ctx_set_device(ctx));
+    const size_t need = (size_t)n * (size_t)(c->nranks + 1);
+    if (need > c->stage_elems) {
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (c->stage) HIP_TRY(ctx, hipFree(c->stage));
+        c->stage = nullptr; c->stage_elems = 0;
+        HIP_TRY(ctx, hipMalloc(&c->stage, need * sizeof(int32_t)));
+        c->stage_elems = need;
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(c->stage, send_host, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+    MSLAM_TRY(mslam_comm_allgather_i32_dev(c, c->stage, n, c->stage + n));
+    HIP_TRY(ctx, hipMemcpyAsync(recv_host, c->stage + n, (size_t)n * 4 * c->nranks, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return MSLAM_OK;
+}
+
+int mslam_comm_destroy(mslam_comm* c)
+{
+    if (!c) return MSLAM_ERR_INVALID;
+    (void)hipSetDevice(c->ctx->device);
+    (void)hipStreamSynchronize(c->ctx->stream);
+    if (c->comm) (void)g_rccl.CommDestroy(c->comm);
+    if (c->stage) (void)hipFree(c->stage);
+    delete c;
+    return MSLAM_OK;
+}
+
+// One process driving ngpu contexts (one per device): rank g contributes send + g*n (host), every rank's gathered vector
+// is identical, so one copy of it (ngpu * n) is returned in recv.
+int mslam_allgather_i32(mslam_ctx* const* ctxs, int ngpu, const int32_t* send, int n, int32_t* recv)
+{
+    if (!ctxs || ngpu < 1 || !send || !recv || n < 1) return MSLAM_ERR_INVALID;
+    for (int g = 0; g < ngpu; g++) if (!ctxs[g]) return MSLAM_ERR_INVALID;
+    mslam_ctx* c0 = ctxs[0];
+    if (!rccl_load()) { c0->last_hip_error = g_rccl.err; return MSLAM_ERR_NO_DEVICE; }
+    std::vector<int> devs(ngpu);
+    for (int g = 0; g < ngpu; g++) devs[g] = ctxs[g]->device;
+    for (int a = 0; a < ngpu; a++) for (int b = a + 1; b < ngpu; b++) if (devs[a] == devs[b]) return MSLAM_ERR_INVALID;
+    AllComm* ac = nullptr;
+    for (auto& e : g_all) if (e.devs == devs) ac = &e;
+    if (!ac) {
+        AllComm e; e.devs = devs; e.comms.resize(ngpu);
+        RCCL_TRY(c0, g_rccl.CommInitAll(e.comms.data(), ngpu, devs.data()));
+        g_all.push_back(e);
+        ac = &g_all.back();
+    }
+    std::vector<int32_t*> bufs(ngpu, nullptr);
+    int status = MSLAM_OK;
+    for (int g = 0; g < ngpu && status == MSLAM_OK; g++) {
+        void* p = nullptr;
+        status = ctx_stage(ctxs[g], (size_t)n * 4 * (ngpu + 1), &p);   // sets the device
+        bufs[g] = (int32_t*)p;
+        if (status == MSLAM_OK && hipMemcpyAsync(bufs[g], send + (size_t)g * n, (size_t)n * 4, hipMemcpyHostToDevice, ctxs[g]->stream) != hipSuccess)
+            status = MSLAM_ERR_HIP;
+    }
+    if (status != MSLAM_OK) return status;
+    RCCL_TRY(c0, g_rccl.GroupStart());
+    for (int g = 0; g < ngpu; g++) {
+        (void)hipSetDevice(devs[g]);
+        ncclResult_t r = g_rccl.AllGather(bufs[g], bufs[g] + n, (size_t)n, ncclInt32, ac->comms[g], ctxs[g]->stream);
+        if (r != ncclSuccess) { (void)g_rccl.GroupEnd(); c0->last_hip_error = std::string("ncclAllGather: ") + g_rccl.GetErrorString(r); return MSLAM_ERR_HIP; }
+    }
+    RCCL_TRY(c0, g_rccl.GroupEnd());
+    for (int g = 0; g < ngpu; g++) {
+        (void)hipSetDevice(devs[g]);
+        if (g == 0) HIP_TRY(c0, hipMemcpyAsync(recv, bufs[0] + n, (size_t)n * 4 * ngpu, hipMemcpyDeviceToHost, ctxs[0]->stream));
+        HIP_TRY(ctxs[g], hipStreamSynchronize(ctxs[g]->stream));
+    }
+    return MSLAM_OK;
+}
+
+} // extern "C"

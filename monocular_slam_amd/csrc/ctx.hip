@@ -133,6 +133,7 @@ void mslam_destroy(mslam_ctx* ctx)
 int mslam_sync(mslam_ctx* ctx)
 {
     if (!ctx) return MSLAM_ERR_INVALID;
+    MSLAM_TRY(ctx_set_device(ctx));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return MSLAM_OK;
 }
@@ -161,14 +162,65 @@ int mslam_dev_free(mslam_ctx* ctx, void* dptr)
 int mslam_memcpy_h2d(mslam_ctx* ctx, void* dst, const void* src, uint64_t bytes)
 {
     if (!ctx || (bytes && (!dst || !src))) return MSLAM_ERR_INVALID;
+    MSLAM_TRY(ctx_set_device(ctx));
     HIP_TRY(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return MSLAM_OK;
+}
+
+int mslam_memcpy_h2d_async(mslam_ctx* ctx, void* dst, const void* src, uint64_t bytes)
+{
+    if (!ctx || (bytes && (!dst || !src))) return MSLAM_ERR_INVALID;
+    MSLAM_TRY(ctx_set_device(ctx));
+    HIP_TRY(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return MSLAM_OK;
+}
+
+int mslam_memcpy_d2h_async(mslam_ctx* ctx, void* dst, const void* src, uint64_t bytes)
+{
+    if (!ctx || (bytes && (!dst || !src))) return MSLAM_ERR_INVALID;
+    MSLAM_TRY(ctx_set_device(ctx));
+    HIP_TRY(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    return MSLAM_OK;
+}
+
+int mslam_memcpy_d2d_async(mslam_ctx* ctx, void* dst, const void* src, uint64_t bytes)
+{
+    if (!ctx || (bytes && (!dst || !src))) return MSLAM_ERR_INVALID;
+    MSLAM_TRY(ctx_set_device(ctx));
+    HIP_TRY(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    return MSLAM_OK;
+}
+
+int mslam_host_alloc(mslam_ctx* ctx, void** hptr, uint64_t bytes)
+{
+    if (!ctx || !hptr) return MSLAM_ERR_INVALID;
+    MSLAM_TRY(ctx_set_device(ctx));
+    HIP_TRY(ctx, hipHostMalloc(hptr, bytes ? bytes : 1, hipHostMallocDefault));
+    return MSLAM_OK;
+}
+
+int mslam_host_free(mslam_ctx* ctx, void* hptr)
+{
+    if (!ctx) return MSLAM_ERR_INVALID;
+    MSLAM_TRY(ctx_set_device(ctx));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipHostFree(hptr));
+    return MSLAM_OK;
+}
+
+int mslam_stream_wait_event(mslam_ctx* ctx, void* ev)
+{
+    if (!ctx || !ev) return MSLAM_ERR_INVALID;
+    MSLAM_TRY(ctx_set_device(ctx));
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, (hipEvent_t)ev, 0));
     return MSLAM_OK;
 }
 
 int mslam_memcpy_d2h(mslam_ctx* ctx, void* dst, const void* src, uint64_t bytes)
 {
     if (!ctx || (bytes && (!dst || !src))) return MSLAM_ERR_INVALID;
+    MSLAM_TRY(ctx_set_device(ctx));
     HIP_TRY(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return MSLAM_OK;
@@ -194,6 +246,7 @@ int mslam_event_destroy(mslam_ctx* ctx, void* ev)
 int mslam_event_record(mslam_ctx* ctx, void* ev)
 {
     if (!ctx || !ev) return MSLAM_ERR_INVALID;
+    MSLAM_TRY(ctx_set_device(ctx));
     HIP_TRY(ctx, hipEventRecord((hipEvent_t)ev, ctx->stream));
     return MSLAM_OK;
 }

@@ -947,6 +947,7 @@ int mslam_orb_extract_batch_dev(mslam_ctx* ctx, const uint8_t* imgs, int B, int 
         (channels != 1 && channels != 3 && channels != 4) || stride < w * channels || frame_stride < (int64_t)stride * h)
         return MSLAM_ERR_INVALID;
     if (((uintptr_t)desc & 7) || ((uintptr_t)kps & 3)) return MSLAM_ERR_INVALID;
+    MSLAM_TRY(ctx_set_device(ctx)); // cached-plan path included: launches must not depend on the caller's current device
     OrbPlan* pl = nullptr;
     MSLAM_TRY(orb_plan_get(ctx, w, h, B, channels, params, &pl));
     OrbDev od = pl->dev;

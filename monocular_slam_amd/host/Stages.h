@@ -64,7 +64,11 @@ private:
 class Optimiser : public ProcessingNode {
 public:
     Optimiser() : ProcessingNode("Optimiser") {}
-    void localBA(DataManager& data, int n_iterations = FULL_BA_ITER);
+    // window <= 0: the reference's behaviour (global BA, frame 0 fixed); window = k: the last k posed frames free, older
+    // ones fixed (Util::LocalBundleAdjustment -- declared, never defined upstream: src/Util.h:27, src/LocalMapper.h:30-42)
+    void localBA(DataManager& data, int n_iterations = FULL_BA_ITER, int window = 0);
     virtual void process(DataManager& data, int frameIdx) override;
     virtual bool validationCheck(DataManager& data, int frameIdx) override;
+    int n_iterations = FULL_BA_ITER;   // src/ParamConfig.h:18 (what Optimiser::process passes upstream, src/Optimiser.cpp:12)
+    int window = 0;                    // process() default = the reference's global BA
 };

@@ -13,13 +13,14 @@
 
 int main(int argc, char** argv)
 {
-    if (argc < 3) { std::fprintf(stderr, "usage: %s in.bin out.txt [--ba] [--nfeatures N] [--no-dist] [--pnp-hyps H] [--pnp-thr T]\n", argv[0]); return 2; }
+    if (argc < 3) { std::fprintf(stderr, "usage: %s in.bin out.txt [--ba] [--ba-window K] [--nfeatures N] [--no-dist] [--pnp-hyps H] [--pnp-thr T]\n", argv[0]); return 2; }
     bool ba = false, nodist = false;
-    int nfeatures = 500, pnpH = 100;
+    int nfeatures = 500, pnpH = 100, baWindow = 0;
     double pnpThr = 8.0;
     for (int i = 3; i < argc; i++) {
         if (!std::strcmp(argv[i], "--ba")) ba = true;
         else if (!std::strcmp(argv[i], "--no-dist")) nodist = true;
+        else if (!std::strcmp(argv[i], "--ba-window") && i + 1 < argc) { ba = true; baWindow = std::atoi(argv[++i]); }
         else if (!std::strcmp(argv[i], "--nfeatures") && i + 1 < argc) nfeatures = std::atoi(argv[++i]);
         else if (!std::strcmp(argv[i], "--pnp-hyps") && i + 1 < argc) pnpH = std::atoi(argv[++i]);
         else if (!std::strcmp(argv[i], "--pnp-thr") && i + 1 < argc) pnpThr = std::atof(argv[++i]);
@@ -51,7 +52,7 @@ int main(int argc, char** argv)
         if (nodist) for (double& d : cpe->distCoeff) d = 0.0;
         slam.addStage(fe);
         slam.addStage(cpe);
-        if (ba) slam.addStage(new Optimiser());
+        if (ba) { Optimiser* opt = new Optimiser(); opt->window = baWindow; slam.addStage(opt); }
         for (int i = 0; i < n; i++) slam.process(dm, i);
         FILE* out = std::fopen(argv[2], "w");
         for (int i = 0; i < n; i++) {

@@ -1,7 +1,7 @@
 // sequence_demo -- src/main.cpp:27-54 of the reference: FrameLoader(directory, begin, end, step).load(dm), then
 // ProcessingPipeline(FeatureExtractor -> CameraPoseEstimator [-> Optimiser]) over every frame.  Output as pipeline_demo:
 // "frame i nfeat r00 .. r23" per frame (+ "gt r00 .. r23" when the data set carries ground truth), "mappoints M", ...
-//   sequence_demo <directory> <begin> <end> <step> out.txt [--ba] [--nfeatures N] [--no-dist] [--pnp-hyps H] [--pnp-thr T]
+//   sequence_demo <directory> <begin> <end> <step> out.txt [--ba] [--ba-window K] [--nfeatures N] [--no-dist] [--pnp-hyps H] [--pnp-thr T]
 #include <cstdio>
 #include <cstring>
 #include "CameraPoseEstimator.h"
@@ -11,13 +11,14 @@
 
 int main(int argc, char** argv)
 {
-    if (argc < 6) { std::fprintf(stderr, "usage: %s directory begin end step out.txt [--ba] [--nfeatures N] [--no-dist] [--pnp-hyps H] [--pnp-thr T]\n", argv[0]); return 2; }
+    if (argc < 6) { std::fprintf(stderr, "usage: %s directory begin end step out.txt [--ba] [--ba-window K] [--nfeatures N] [--no-dist] [--pnp-hyps H] [--pnp-thr T]\n", argv[0]); return 2; }
     bool ba = false, nodist = false;
-    int nfeatures = 500, pnpH = 100;
+    int nfeatures = 500, pnpH = 100, baWindow = 0;
     double pnpThr = 8.0;
     for (int i = 6; i < argc; i++) {
         if (!std::strcmp(argv[i], "--ba")) ba = true;
         else if (!std::strcmp(argv[i], "--no-dist")) nodist = true;
+        else if (!std::strcmp(argv[i], "--ba-window") && i + 1 < argc) { ba = true; baWindow = std::atoi(argv[++i]); }
         else if (!std::strcmp(argv[i], "--nfeatures") && i + 1 < argc) nfeatures = std::atoi(argv[++i]);
         else if (!std::strcmp(argv[i], "--pnp-hyps") && i + 1 < argc) pnpH = std::atoi(argv[++i]);
         else if (!std::strcmp(argv[i], "--pnp-thr") && i + 1 < argc) pnpThr = std::atof(argv[++i]);
@@ -35,7 +36,7 @@ int main(int argc, char** argv)
         if (nodist) for (double& d : cpe->distCoeff) d = 0.0;
         slam.addStage(fe);
         slam.addStage(cpe);
-        if (ba) slam.addStage(new Optimiser());
+        if (ba) { Optimiser* opt = new Optimiser(); opt->window = baWindow; slam.addStage(opt); }
         const int n = (int)dm.frames.size();
         for (int i = 0; i < n; i++) slam.process(dm, i);
         FILE* out = std::fopen(argv[5], "w");

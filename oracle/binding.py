@@ -127,6 +127,15 @@ def orb_level(img: np.ndarray, params: OrbParams, level: int, blurred: bool):
     return out[: lw.value * lh.value].reshape(lh.value, lw.value).copy()
 
 
+def fast_score_map(img: np.ndarray, thr: int = 20, nms: bool = False) -> np.ndarray:
+    """FAST-9/16 cornerScore map of a gray image, before (default) or after the 3x3 non-max suppression."""
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w = img.shape
+    out = np.zeros((h, w), np.uint8)
+    (lib().orc_fast_nms_map if nms else lib().orc_fast_score_map)(_p(img, u8p), w, h, w, thr, _p(out, u8p))
+    return out
+
+
 def match_knn2(q: np.ndarray, t: np.ndarray):
     q = np.ascontiguousarray(q, dtype=np.uint8); t = np.ascontiguousarray(t, dtype=np.uint8)
     nq, nt = q.shape[0], t.shape[0]

@@ -45,6 +45,8 @@ void orc_bgr2gray(const uint8_t* src, int w, int h, int stride, int channels, ui
 void orc_resize_linear_u8(const uint8_t* src, int sw, int sh, int sstride, uint8_t* dst, int dw, int dh, int dstride);
 void orc_gaussian_blur7(const uint8_t* src, int w, int h, int sstride, uint8_t* dst, int dstride);
 void orc_gaussian_kernel7_q8(int k[7]);
+/* FAST-9/16 score map before non-max suppression: out[y*w+x] = score (>= thr) of every segment-test corner, else 0 */
+void orc_fast_score_map(const uint8_t* img, int w, int h, int stride, int thr, uint8_t* out);
 /* FAST-9/16 score map after 3x3 non-max suppression: out[y*w+x] = score (>= thr) or 0 */
 void orc_fast_nms_map(const uint8_t* img, int w, int h, int stride, int thr, uint8_t* out);
 float orc_harris_response(const uint8_t* img, int stride, int x, int y);

@@ -220,16 +220,24 @@ static inline int fast_score(const uint8_t* p, const int* ofs, int thr)
     return best - 1;           /* cornerScore: threshold = -b0 - 1 */
 }
 
-void orc_fast_nms_map(const uint8_t* img, int w, int h, int stride, int thr, uint8_t* out)
+/* FAST-9/16 score map BEFORE non-max suppression: out[y*w+x] = cornerScore (>= thr) for every pixel that passes the
+ * segment test, 0 elsewhere (and in the 3-pixel border FAST_t skips). */
+void orc_fast_score_map(const uint8_t* img, int w, int h, int stride, int thr, uint8_t* out)
 {
     int ofs[16];
     for (int k = 0; k < 16; k++) ofs[k] = ring_dy[k] * stride + ring_dx[k];
-    uint8_t* sc = (uint8_t*)calloc((size_t)w * h, 1);
     memset(out, 0, (size_t)w * h);
     /* FAST_t: corners for 3 <= x < w-3, 3 <= y < h-3; everything else scores 0 */
     for (int y = 3; y < h - 3; y++)
         for (int x = 3; x < w - 3; x++)
-            sc[(size_t)y * w + x] = (uint8_t)fast_score(img + (size_t)y * stride + x, ofs, thr);
+            out[(size_t)y * w + x] = (uint8_t)fast_score(img + (size_t)y * stride + x, ofs, thr);
+}
+
+void orc_fast_nms_map(const uint8_t* img, int w, int h, int stride, int thr, uint8_t* out)
+{
+    uint8_t* sc = (uint8_t*)malloc((size_t)w * h);
+    orc_fast_score_map(img, w, h, stride, thr, sc);
+    memset(out, 0, (size_t)w * h);
     for (int y = 3; y < h - 3; y++)
         for (int x = 3; x < w - 3; x++) {
             int s = sc[(size_t)y * w + x];

@@ -425,3 +425,26 @@ def test_descriptor_trig_kernel_equals_libm_after_float_cast(tmp_path):
     r = subprocess.run([str(exe), "5"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout
     assert "differences 0" in r.stdout
+
+
+# ---------------------------------------------------------------- independent cross-check (scikit-image 0.18.3)
+def test_oracle_fast_and_hamming_agree_with_scikit_image_vectors(oracle):
+    """tests/golden/skimage_crosscheck.npz was written by the one independent implementation in the build image
+    (scikit-image 0.18.3, tests/golden/make_skimage_crosscheck.py).  It is NOT the reference and pins nothing about
+    OpenCV 2.4.13 -- parity stays unpinned -- but it is evidence that does not come from this repository: the oracle's
+    FAST-9/16 segment-test set (before non-max suppression, threshold 20, strict comparisons) and its brute-force
+    Hamming nearest neighbour (ties to the lower train index) must agree with it exactly."""
+    z = np.load(os.path.join(GOLD, "skimage_crosscheck.npz"))
+    for seed in (11, 12):
+        img = z[f"img_{seed}"]
+        mask = np.unpackbits(z[f"fast_mask_{seed}"])[: img.size].reshape(img.shape).astype(bool)
+        mine = oracle.fast_score_map(img, 20) > 0
+        assert mask.sum() > 300                      # a meaningful number of corners
+        assert (mine == mask).all(), (int(mine.sum()), int(mask.sum()), int((mine != mask).sum()))
+        # and the scores the oracle attaches are >= the threshold wherever the segment test passes
+        assert (oracle.fast_score_map(img, 20)[mask] >= 20).all()
+    for seed in (21, 22):
+        a, b, nn = z[f"desc_a_{seed}"], z[f"desc_b_{seed}"], z[f"nn_{seed}"]
+        rc, idx, dist = oracle.match_knn2(a, b)
+        assert rc == 0 and (idx[:, 0] == nn).all()
+        assert (b[5] == b[3]).all() and (idx[:, 0] != 5).all() and (idx[:, 0] != 200).all()   # duplicates: the lower index wins

@@ -92,6 +92,28 @@ def test_optimiser_stage_reduces_robust_chi2(tmp_path, sequence):
     assert _rot_angle(poses[2][:, :3], gt[2][0]) < 1.0
 
 
+def test_local_ba_window_keeps_older_frames_fixed(tmp_path, sequence):
+    """Optimiser::localBA(data, n, window): window = 1 frees only the newest posed frame, so the pose frame 1 got while it was
+    the newest one survives every later BA bit for bit; with window <= 0 (the reference's global BA, src/Optimiser.cpp:6-18)
+    later BAs move it.  chi2 decreases either way and frame 0 stays the gauge."""
+    frames, gt = sequence
+    flags = ("--no-dist", "--pnp-hyps", "256", "--pnp-thr", "3.0")
+    p2, _, _, _ = _run_demo(tmp_path, frames[:2], synth.K_TUM1, *flags, "--ba-window", "1")
+    p4, _, pts, chi = _run_demo(tmp_path, frames, synth.K_TUM1, *flags, "--ba-window", "1")
+    np.testing.assert_array_equal(p4[0], np.eye(3, 4))
+    np.testing.assert_array_equal(p4[1], p2[1])
+    assert chi is not None and len(chi) >= 2 and (np.diff(chi) <= 1e-9 * chi[0]).all()
+    g2, _, _, _ = _run_demo(tmp_path, frames[:2], synth.K_TUM1, *flags, "--ba")
+    g4, _, _, _ = _run_demo(tmp_path, frames, synth.K_TUM1, *flags, "--ba")
+    np.testing.assert_array_equal(g2[1], p2[1])          # with two frames the window and the global problem coincide
+    assert np.abs(g4[1] - g2[1]).max() > 1e-9            # global BA keeps refining frame 1
+    for i in (2, 3):
+        assert _rot_angle(p4[i][:, :3], gt[i][0]) < 1.0
+    # the sequence demo exposes the same switch (src/main.cpp:43's commented-out stage, parameterised)
+    r = subprocess.run([os.path.join(ROOT, "monocular_slam_amd", "host", "mslam_sequence_demo")], capture_output=True, text=True)
+    assert "--ba-window" in r.stderr
+
+
 def test_frame_loader_sequence_matches_raw_pipeline(tmp_path, sequence):
     """f2: FrameLoader (TUM-style tree: rgb/<timestamp>.png, groundtruth.txt) -> ProcessingPipeline gives what the raw-frame
     demo gives on the same pixels and intrinsics; ground truth is attached to the frames as the reference does."""
