@@ -331,13 +331,28 @@ int mslam_ba_plan_download(mslam_ba_plan* plan, mslam_ba_system* s);
  * The caller solves S x_p = b_s (small, host), then mslam_ba_plan_backsub_dev computes x_l = Hll^-1 (b_l - Hpl^T x_p)
  * on the device, optionally applies X += x_l to the plan's points, and reduces sum x_l (lambda x_l + b_l)
  * (the landmark part of LM's computeScale).  mslam_ba_plan_points_snapshot_dev(restore=0/1) saves / restores the
- * points for rejected LM steps.  MSLAM_ERR_CAPACITY if the plan was built without Schur scratch. */
+ * points for rejected LM steps.  MSLAM_ERR_CAPACITY if the plan was built without Schur scratch (a tile of 64
+ * consecutive points observed by more than 64 different free poses: solve that system on the host from the blocks).
+ * A graph with two edges between the same pose and point is refused by mslam_ba_plan_create (MSLAM_ERR_INVALID): g2o
+ * would accumulate them into one block, this layout gives every edge its own. */
 int mslam_ba_plan_schur_dev(mslam_ba_plan* plan, double lambda);
 int mslam_ba_plan_download_schur(mslam_ba_plan* plan, double* S, double* b_s);
 int mslam_ba_plan_backsub_dev(mslam_ba_plan* plan, const double* x_pose_host, int apply_to_points);
 int mslam_ba_plan_download_x(mslam_ba_plan* plan, double* x /* 6 fp + 3 n_points, optional */, double* scale_landmarks /* optional */);
 int mslam_ba_plan_points_snapshot_dev(mslam_ba_plan* plan, int restore);
 int mslam_ba_plan_get_state(mslam_ba_plan* plan, double* poses_host, double* points_host);
+
+/* Windows: several independent local-BA problems concatenated block-diagonally into one plan (what a multi-stream host
+ * does with the sliding windows of its streams; the reference optimises one graph at a time, src/Optimiser.cpp:6-18).
+ * pose_window (n_poses) / point_window (n_points) name the window of every vertex (fixed poses: any valid id).  After
+ * this call lambda is per window: mslam_ba_plan_schur_windows_dev takes n_windows values (mslam_ba_plan_schur_dev keeps
+ * working and uses one value for all), every build additionally reduces the robust chi2 per window and every
+ * back-substitution the landmark part of LM's computeScale per window (mslam_ba_plan_download_window_sums), so that one
+ * Levenberg-Marquardt trial of every window runs per launch sequence. */
+int mslam_ba_plan_set_windows(mslam_ba_plan* plan, const int32_t* pose_window, const int32_t* point_window, int n_windows);
+int mslam_ba_plan_schur_windows_dev(mslam_ba_plan* plan, const double* lambda_per_window_host);
+int mslam_ba_plan_download_window_sums(mslam_ba_plan* plan, double* robust_chi2 /* n_windows, optional */,
+                                       double* scale_landmarks /* n_windows, optional */);
 
 /* ---- multi-GPU -------------------------------------------------------------------------
  * The path shards by independent streams (one process per GPU, no data-path collective).

@@ -323,6 +323,21 @@ class BaPlan:
     def schur_dev(self, lam: float):
         self.ctx._check(lib().mslam_ba_plan_schur_dev(self._h, C.c_double(lam)), "mslam_ba_plan_schur_dev")
 
+    def set_windows(self, pose_window, point_window, n_windows: int):
+        a = np.ascontiguousarray(pose_window, np.int32); b = np.ascontiguousarray(point_window, np.int32)
+        self.n_windows = n_windows
+        self.ctx._check(lib().mslam_ba_plan_set_windows(self._h, _p(a, i32p), _p(b, i32p), n_windows), "mslam_ba_plan_set_windows")
+
+    def schur_windows_dev(self, lam):
+        a = np.ascontiguousarray(lam, np.float64)
+        assert a.size == self.n_windows
+        self.ctx._check(lib().mslam_ba_plan_schur_windows_dev(self._h, _p(a, f64p)), "mslam_ba_plan_schur_windows_dev")
+
+    def download_window_sums(self):
+        chi = np.zeros(self.n_windows); sc = np.zeros(self.n_windows)
+        self.ctx._check(lib().mslam_ba_plan_download_window_sums(self._h, _p(chi, f64p), _p(sc, f64p)), "mslam_ba_plan_download_window_sums")
+        return chi, sc
+
     def download_schur(self):
         n6 = 6 * self.view.n_free_poses
         S = np.zeros((n6, n6)); bs = np.zeros(n6)

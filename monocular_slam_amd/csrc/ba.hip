@@ -1,28 +1,39 @@
 // ba.hip -- K9: bundle-adjustment linearisation on gfx950: reprojection residuals, Huber
 // weights, analytic 2x3 / 2x6 Jacobians and the J^T w Omega J blocks, written straight into the
-// block layout the host-side Schur / LDL^T solve consumes (Hpp, Hll, block-CSR Hpl, b).
+// block layout the host-side Schur / LDL^T solve consumes (Hpp, Hll, block-CSR Hpl, b); plus the Schur
+// complement and the landmark back-substitution of the same system.
 //
 // Stands in for one pass of BlockSolver<6,3>::buildSystem (reference ThirdParty/g2o/g2o/core/
 // block_solver.hpp:502-560) over the graph of Util::BundleAdjustment (src/Util.cpp:34-170):
 // EdgeSE3ProjectXYZ::computeError / linearizeOplus (types/types_six_dof_expmap.h:90-95,
 // types_six_dof_expmap.cpp:103-139), RobustKernelHuber::robustify (core/robust_kernel_impl.cpp:78-91),
-// BaseBinaryEdge::constructQuadraticForm (core/base_binary_edge.hpp:55-120).
+// BaseBinaryEdge::constructQuadraticForm (core/base_binary_edge.hpp:55-120); and for
+// BlockSolver::solve (block_solver.hpp:354-486).
 //
-// HBM layout (device-resident plan, built once per graph like g2o's buildStructure):
+// HBM layout (device-resident plan, built once per graph like g2o's buildStructure).  Edges are re-ordered once, on the
+// host, into ROW ORDER k: rows = poses with at least one edge, free poses first (in free-index order) then fixed ones;
+// inside a row by point.  For a free row k IS the index of the edge's 6x3 Hpl block in the block-CSR (so the kernel
+// that evaluates an edge writes its block to consecutive memory), and every per-edge input is a streaming read:
 //   state    poses f64[n_poses][7] (t, q xyzw), points f64[n_points][3]
-//   edges    edge_pose/edge_point i32[E], obs f64[E][2], info f64[E], intr f64[n_poses][4]
-//   by point pt_ptr i32[n_points+1], pt_edge i32[E]   (edges of a point, ascending edge id)
-//   Hpl      rowptr i32[fp+1], col i32[nnzb], val f64[nnzb][6][3] (row = free pose, col = point,
-//            sorted by point), blk_edge i32[nnzb] (edge of a block), slot i32[E] (block of an edge)
-// Kernels:
-//   ba_points_k  16 lanes per point: lane l takes the point's edges l, l+16, ...: residual, Huber
-//                weight, Jacobians, writes err/chi2/rho1 and the edge's 6x3 Hpl block, keeps the 3x3
-//                Hll / b_l contribution in registers; a fixed-order butterfly over the 16 lanes sums
-//                them (no float atomics: results are run-to-run identical)
-//   ba_poses_k   grid (free pose, chunk): one lane per Hpl block of the pose recomputes B and the
-//                weight (cheaper than re-reading 216 B per edge) and a fixed-tree block reduction
-//                produces the chunk's 6x6 (21 unique) + 6 sums
+//   rows     erowptr i32[R+1], row_pose i32[R]; rec i32x2[E] (point, original edge id), obs_k f64x2[E]
+//   by point pt_ptr i32[n_points+1], pt_k i32[E]   (row-order indices of a point's edges, ascending)
+//   ptside   f64[10][E]   per-edge point-side contributions (6 Hll + 3 b_l + rho), plane-major: coalesced both ways
+// Kernels of one linearisation (no float atomics anywhere: every sum has a fixed shape, results are run-to-run identical):
+//   ba_edges_k   grid (chunk, row), one lane per edge: residual, Huber weight, Jacobians ONCE per edge; err/chi2/rho1 by
+//                edge id; the point-side terms into ptside; for free rows the 6x3 block goes through an LDS transpose and
+//                leaves as 16-byte stores of consecutive memory, and the 27 pose-side sums are reduced by a wavefront
+//                butterfly + 4 wavefront partials into the chunk's partial
+//   ba_points_k  one lane per point: adds its edges' ptside rows in row order -> Hll, b_l, robust chi2 of the point
 //   ba_final_k   adds the chunk partials per pose in chunk order, reduces the robust chi2
+// Schur complement (tiles of SCHUR_TP consecutive points; a tile's pose list and its dense point x local-pose block table
+// are plan data, O(points x poses-per-tile) instead of the dense poses x points table):
+//   ba_schur_points_k  (Hll + lambda I)^-1 and its product with b_l, per point
+//   ba_schur_tiles_k   per tile: blocks staged once through LDS with B Dinv formed on the way; per local pose pair the sum
+//                      over the tile's points of (B Dinv)_j1 B_j2^T in registers; per local pose the sum of B (Dinv b_l)
+//   ba_schur_final_k   S block (j1, j2) = [Hpp + lambda I] - sum of the tile partials in tile order; b_s
+//   ba_backsub_k / ba_window_sums_k   x_l, X += x_l, and the per-window sums of LM's computeScale and chi2
+// lambda may differ per WINDOW (mslam_ba_plan_set_windows): block-diagonal batches of independent local-BA windows then
+// run one LM trial of every window per launch.
 // f64 throughout (g2o is double; 1e-4 relative parity is an f64 target).  FMA contraction is
 // allowed in this file: no discrete decision depends on the last bit here.
 #include "common.h"
@@ -35,40 +46,58 @@
 
 namespace {
 
-constexpr int GROUP = 16;          // lanes per point
-constexpr int BA_THREADS = 256;
-constexpr int POSE_CHUNK = 256;    // Hpl blocks per pose-chunk workgroup
+constexpr int EDGE_CHUNK = 256;    // edges per ba_edges_k workgroup
+constexpr int T_PITCH = 258;       // LDS plane pitch (doubles) of the block transpose: 258 = 2 (mod 32) spreads the planes over banks
+constexpr int SCHUR_TP = 64;       // points per Schur tile
+constexpr int SCHUR_NSUB = 4;      // point subsets per (tile, pair): adjacent lanes, summed by a 2-step butterfly
+constexpr int SCHUR_LMAX = 64;     // local poses per tile beyond which the device Schur path is not offered
 
 struct BaDev {
-    int n_poses, n_points, n_edges, n_free, nnzb, n_chunks_max;
+    int n_poses, n_points, n_edges, n_free, nnzb, n_rows, n_chunks_max;
     double huber_delta; float dsqr;
     const double* poses; const double* points;
-    const int32_t* edge_pose; const int32_t* edge_point; const double* obs; const double* info; const double* intr;
+    const int32_t* edge_pose; const double* info; const double* intr;
     const int32_t* fidx;      // free index per pose or -1
-    const int32_t* pt_ptr; const int32_t* pt_edge;
-    const int32_t* rowptr; const int32_t* blk_edge; const int32_t* slot;
+    const int32_t* erowptr; const int32_t* row_pose;
+    const int2* rec;          // [E] {point, edge id} in row order
+    const double2* obs_k;     // [E] observation in row order
+    const int32_t* pt_ptr; const int32_t* pt_k;
+    const int32_t* blk_row;   // [nnzb] free row of a block
     double* err; double* chi2; double* rho1; double* Hpp; double* Hll; double* Hpl_val; double* b;
+    double* ptside;           // [10][E]
     double* pt_rho;           // [n_points] robust chi2 per point
     double* chi_part;         // [ceil(n_points / 4096)] slice sums of pt_rho (large problems)
     double* pose_part;        // [n_free][n_chunks_max][27]
     double* robust_chi2;      // [1]
     // ---- Schur complement (f1): reduced pose system S x_p = b_s, landmark back-substitution
     const int32_t* col;       // [nnzb] point of a block
-    const int32_t* blk_of;    // [n_free][n_points] block of (pose row, point) or -1
+    int n_tiles; long long n_tile_pairs;
+    const int32_t* tile_pose_ptr; const int32_t* tile_pose;   // local pose list of a tile (free row ids, ascending)
+    const int32_t* tile_blk_ptr;  const int32_t* tile_blk;    // [tile][SCHUR_TP][L] block of (point, local pose) or -1
+    const long long* tile_out_ptr;                            // first partial (36 doubles each) of a tile
+    int n_gpairs; const int32_t* gpair_j; const int32_t* gpair_ptr; const long long* gpair_src; // global pose pairs and their partials
+    const int32_t* gdiag;     // [n_free] global pair index of (j, j) or -1
+    double* tile_part;        // [n_tile_pairs][36]
+    double* tile_coef;        // [n_tile_pairs][6] (diagonal local pairs only)
     double* Dinv;             // [n_points][9]  (Hll + lambda I)^-1
     double* db;               // [n_points][3]  Dinv b_l
-    double* BD;               // [nnzb][18]     B Dinv
-    double* cblk;             // [nnzb][6]      B (Dinv b_l)
-    double* pair_part;        // [npairs][n_chunks_max][36]
-    double* coef_part;        // [n_free][n_chunks_max][6]
     double* S;                // [6 n_free][6 n_free]
     double* bs;               // [6 n_free]
     double* x;                // [6 n_free + 3 n_points]
     double* points_bk;        // [n_points][3] snapshot for rejected LM steps
-    double* scale_part;       // [ceil(n_points/256)] partial sums of x_l (lambda x_l + b_l)
+    double* pt_scale;         // [n_points] x_l . (lambda x_l + b_l)
+    double* scale_part;       // [ceil(n_points/4096)]
     double* scale_l;          // [1]
-    double lambda;
+    // ---- windows (independent sub-problems concatenated block-diagonally): lambda per window
+    int n_windows;
+    const int32_t* pose_win; const int32_t* point_win;        // window of a free row / of a point (null: one window)
+    const int32_t* win_pt_ptr; const int32_t* win_pt;         // points of a window
+    const double* lam_w;      // [n_windows] (device)
+    double* win_out;          // [n_windows][2]: robust chi2, landmark part of computeScale
 };
+
+__device__ __forceinline__ double lam_pose(const BaDev& d, int f) { return d.lam_w[d.pose_win ? d.pose_win[f] : 0]; }
+__device__ __forceinline__ double lam_point(const BaDev& d, int i) { return d.lam_w[d.point_win ? d.point_win[i] : 0]; }
 
 struct EdgeLin { double e0, e1, A[6], B[12]; };
 
@@ -112,114 +141,120 @@ __device__ __forceinline__ void huber(double chi2, double delta, float dsqr, dou
     }
 }
 
-__global__ __launch_bounds__(BA_THREADS)
-void ba_points_k(BaDev d)
+// fixed-shape workgroup sum of NV values per lane: xor butterfly inside each wavefront (registers), then the 4 wavefront
+// sums in index order by thread q < NV; the result of value q is returned to thread q (others get garbage)
+template <int NV>
+__device__ __forceinline__ double chunk_reduce(double (&v)[NV], double* s_red /* NV * 4 */, int tid)
 {
-    const int gid = (blockIdx.x * BA_THREADS + threadIdx.x) / GROUP; // point
-    const int gl = threadIdx.x & (GROUP - 1);
-    const bool live = gid < d.n_points;
-    double acc[13]; // Hll upper (6): 00 01 02 11 12 22; b_l (3); rho (1); pad
 #pragma unroll
-    for (int k = 0; k < 13; k++) acc[k] = 0.0;
-    if (live) {
-        const double X0 = d.points[3 * gid], X1 = d.points[3 * gid + 1], X2 = d.points[3 * gid + 2];
-        const int e0 = d.pt_ptr[gid], e1 = d.pt_ptr[gid + 1];
-        for (int k = e0 + gl; k < e1; k += GROUP) {
-            const int e = d.pt_edge[k];
-            const int jp = d.edge_pose[e];
-            const double* in = d.intr + 4 * jp;
-            EdgeLin L;
-            edge_eval(d.poses + 7 * jp, X0, X1, X2, d.obs[2 * e], d.obs[2 * e + 1], in[0], in[1], in[2], in[3], L);
-            const double om = d.info[e];
-            const double chi2 = L.e0 * (om * L.e0) + L.e1 * (om * L.e1);
-            double rho0, rho1;
-            huber(chi2, d.huber_delta, d.dsqr, rho0, rho1);
-            d.err[2 * e] = L.e0; d.err[2 * e + 1] = L.e1; d.chi2[e] = chi2; d.rho1[e] = rho1;
-            const double wom = rho1 * om;
-            const double r0 = -(om * L.e0) * rho1, r1 = -(om * L.e1) * rho1;
-            const double* A = L.A;
-            acc[0] += wom * (A[0] * A[0] + A[3] * A[3]); acc[1] += wom * (A[0] * A[1] + A[3] * A[4]);
-            acc[2] += wom * (A[0] * A[2] + A[3] * A[5]); acc[3] += wom * (A[1] * A[1] + A[4] * A[4]);
-            acc[4] += wom * (A[1] * A[2] + A[4] * A[5]); acc[5] += wom * (A[2] * A[2] + A[5] * A[5]);
-            acc[6] += A[0] * r0 + A[3] * r1; acc[7] += A[1] * r0 + A[4] * r1; acc[8] += A[2] * r0 + A[5] * r1;
-            acc[9] += rho0;
-            const int sl = d.slot[e];
-            if (sl >= 0) { // B^T (w Omega) A, row-major 6x3
-                double* Hb = d.Hpl_val + (size_t)sl * 18;
+    for (int o = 32; o > 0; o >>= 1)
 #pragma unroll
-                for (int a = 0; a < 6; a++) {
-                    const double ba = wom * L.B[a], bb = wom * L.B[6 + a];
-                    Hb[a * 3 + 0] = ba * A[0] + bb * A[3];
-                    Hb[a * 3 + 1] = ba * A[1] + bb * A[4];
-                    Hb[a * 3 + 2] = ba * A[2] + bb * A[5];
-                }
-            }
-        }
-    }
-    // fixed-order butterfly over the 16 lanes of the group
+        for (int q = 0; q < NV; q++) v[q] += __shfl_xor(v[q], o);
+    if ((tid & 63) == 0)
 #pragma unroll
-    for (int o = GROUP / 2; o > 0; o >>= 1)
-#pragma unroll
-        for (int k = 0; k < 10; k++) acc[k] += __shfl_xor(acc[k], o, GROUP);
-    if (live && gl == 0) {
-        double* H = d.Hll + (size_t)gid * 9;
-        H[0] = acc[0]; H[1] = acc[1]; H[2] = acc[2];
-        H[3] = acc[1]; H[4] = acc[3]; H[5] = acc[4];
-        H[6] = acc[2]; H[7] = acc[4]; H[8] = acc[5];
-        double* bl = d.b + 6 * d.n_free + 3 * (size_t)gid;
-        bl[0] = acc[6]; bl[1] = acc[7]; bl[2] = acc[8];
-        d.pt_rho[gid] = acc[9];
-    }
+        for (int q = 0; q < NV; q++) s_red[q * 4 + (tid >> 6)] = v[q];
+    __syncthreads();
+    double t = 0.0;
+    if (tid < NV) t = ((s_red[tid * 4] + s_red[tid * 4 + 1]) + s_red[tid * 4 + 2]) + s_red[tid * 4 + 3];
+    return t;
 }
 
-__global__ __launch_bounds__(POSE_CHUNK)
-void ba_poses_k(BaDev d)
+__global__ __launch_bounds__(EDGE_CHUNK)
+void ba_edges_k(BaDev d)
 {
-    const int f = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
-    const int k0 = d.rowptr[f], k1 = d.rowptr[f + 1];
-    const int k = k0 + chunk * POSE_CHUNK + tid;
-    if (k0 + chunk * POSE_CHUNK >= k1) return; // whole block out of range
-    __shared__ double s_red[27 * (POSE_CHUNK / 64)];
-    double v[27];
+    const int r = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
+    const int k0 = d.erowptr[r], k1 = d.erowptr[r + 1];
+    const int kb = k0 + chunk * EDGE_CHUNK;
+    if (kb >= k1) return; // whole workgroup out of range
+    __shared__ double s_t[18 * T_PITCH];
+    __shared__ double s_red[27 * 4];
+    const int k = kb + tid;
+    const int jp = d.row_pose[r];          // the whole row shares one pose: uniform (scalar) loads
+    const int f = d.fidx[jp];
+    const bool live = k < k1;
+    double v[27], Hb[18];
 #pragma unroll
     for (int q = 0; q < 27; q++) v[q] = 0.0;
-    if (k < k1) {
-        const int e = d.blk_edge[k];
-        const int jp = d.edge_pose[e], ip = d.edge_point[e];
+#pragma unroll
+    for (int q = 0; q < 18; q++) Hb[q] = 0.0;
+    if (live) {
+        const int2 rc = d.rec[k];
+        const double2 ob = d.obs_k[k];
+        const int ip = rc.x, e = rc.y;
         const double* in = d.intr + 4 * jp;
         EdgeLin L;
-        edge_eval(d.poses + 7 * jp, d.points[3 * ip], d.points[3 * ip + 1], d.points[3 * ip + 2], d.obs[2 * e], d.obs[2 * e + 1],
-                  in[0], in[1], in[2], in[3], L);
+        edge_eval(d.poses + 7 * jp, d.points[3 * ip], d.points[3 * ip + 1], d.points[3 * ip + 2], ob.x, ob.y, in[0], in[1], in[2], in[3], L);
         const double om = d.info[e];
         const double chi2 = L.e0 * (om * L.e0) + L.e1 * (om * L.e1);
         double rho0, rho1;
         huber(chi2, d.huber_delta, d.dsqr, rho0, rho1);
+        d.err[2 * e] = L.e0; d.err[2 * e + 1] = L.e1; d.chi2[e] = chi2; d.rho1[e] = rho1;
         const double wom = rho1 * om;
         const double r0 = -(om * L.e0) * rho1, r1 = -(om * L.e1) * rho1;
-        int q = 0;
+        const double* A = L.A;
+        const size_t E = (size_t)d.n_edges;
+        double* ps = d.ptside + k;
+        ps[0] = wom * (A[0] * A[0] + A[3] * A[3]);     ps[E] = wom * (A[0] * A[1] + A[3] * A[4]);
+        ps[2 * E] = wom * (A[0] * A[2] + A[3] * A[5]); ps[3 * E] = wom * (A[1] * A[1] + A[4] * A[4]);
+        ps[4 * E] = wom * (A[1] * A[2] + A[4] * A[5]); ps[5 * E] = wom * (A[2] * A[2] + A[5] * A[5]);
+        ps[6 * E] = A[0] * r0 + A[3] * r1; ps[7 * E] = A[1] * r0 + A[4] * r1; ps[8 * E] = A[2] * r0 + A[5] * r1;
+        ps[9 * E] = rho0;
+        if (f >= 0) {
 #pragma unroll
-        for (int a = 0; a < 6; a++)
+            for (int a = 0; a < 6; a++) { // B^T (w Omega) A, row-major 6x3
+                const double ba = wom * L.B[a], bb = wom * L.B[6 + a];
+                Hb[a * 3 + 0] = ba * A[0] + bb * A[3];
+                Hb[a * 3 + 1] = ba * A[1] + bb * A[4];
+                Hb[a * 3 + 2] = ba * A[2] + bb * A[5];
+            }
+            int q = 0;
 #pragma unroll
-            for (int c = a; c < 6; c++) v[q++] = wom * (L.B[a] * L.B[c] + L.B[6 + a] * L.B[6 + c]);
+            for (int a = 0; a < 6; a++)
 #pragma unroll
-        for (int a = 0; a < 6; a++) v[21 + a] = L.B[a] * r0 + L.B[6 + a] * r1;
+                for (int c = a; c < 6; c++) v[q++] = wom * (L.B[a] * L.B[c] + L.B[6 + a] * L.B[6 + c]);
+#pragma unroll
+            for (int a = 0; a < 6; a++) v[21 + a] = L.B[a] * r0 + L.B[6 + a] * r1;
+        }
     }
-    // fixed-shape reduction: xor butterfly inside each wavefront (registers), then the 4 wavefront sums in index order
-    // (replaces a 55 KiB LDS tree that allowed only two workgroups per CU)
+    if (f < 0) return; // fixed pose (uniform): no Hpl row, no pose block
+    // the workgroup's blocks are consecutive in Hpl_val: transpose through LDS ([value][lane] planes) and write 16-byte
+    // pieces of consecutive memory instead of 18 stride-144 doubles per lane
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1)
-#pragma unroll
-        for (int q = 0; q < 27; q++) v[q] += __shfl_xor(v[q], o);
-    if ((tid & 63) == 0)
-#pragma unroll
-        for (int q = 0; q < 27; q++) s_red[q * (POSE_CHUNK / 64) + (tid >> 6)] = v[q];
+    for (int q = 0; q < 18; q++) s_t[q * T_PITCH + tid] = Hb[q];
     __syncthreads();
-    if (tid < 27) {
-        double t = s_red[tid * (POSE_CHUNK / 64)];
-#pragma unroll
-        for (int w = 1; w < POSE_CHUNK / 64; w++) t += s_red[tid * (POSE_CHUNK / 64) + w];
-        d.pose_part[((size_t)f * d.n_chunks_max + chunk) * 27 + tid] = t;
+    {
+        const int n_live = min(EDGE_CHUNK, k1 - kb);
+        double2* out = reinterpret_cast<double2*>(d.Hpl_val + (size_t)kb * 18);   // (kb * 144) bytes: 16-byte aligned
+        for (int c = tid; c < n_live * 9; c += EDGE_CHUNK) {
+            const int kl = c / 9, q = 2 * (c - 9 * kl);
+            out[c] = make_double2(s_t[q * T_PITCH + kl], s_t[(q + 1) * T_PITCH + kl]);
+        }
     }
+    const double t = chunk_reduce<27>(v, s_red, tid);
+    if (tid < 27) d.pose_part[((size_t)f * d.n_chunks_max + chunk) * 27 + tid] = t;
+}
+
+__global__ __launch_bounds__(256)
+void ba_points_k(BaDev d)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= d.n_points) return;
+    double acc[10];
+#pragma unroll
+    for (int q = 0; q < 10; q++) acc[q] = 0.0;
+    const size_t E = (size_t)d.n_edges;
+    for (int kk = d.pt_ptr[i]; kk < d.pt_ptr[i + 1]; kk++) {   // ascending row order: a fixed summation order
+        const double* ps = d.ptside + d.pt_k[kk];
+#pragma unroll
+        for (int q = 0; q < 10; q++) acc[q] += ps[q * E];
+    }
+    double* H = d.Hll + (size_t)i * 9;
+    H[0] = acc[0]; H[1] = acc[1]; H[2] = acc[2];
+    H[3] = acc[1]; H[4] = acc[3]; H[5] = acc[4];
+    H[6] = acc[2]; H[7] = acc[4]; H[8] = acc[5];
+    double* bl = d.b + 6 * d.n_free + 3 * (size_t)i;
+    bl[0] = acc[6]; bl[1] = acc[7]; bl[2] = acc[8];
+    d.pt_rho[i] = acc[9];
 }
 
 // Final reductions.  Small problems (one local-BA window): ONE workgroup does both the per-pose chunk sums and the
@@ -237,7 +272,7 @@ void ba_final_k(BaDev d, int n_pose_wg)
         const int i0 = single ? tid : (int)blockIdx.x * 256 + tid, step = single ? 256 : d.n_free * 27;
         for (int i = i0; i < d.n_free * 27; i += step) {
             const int f = i / 27, q = i % 27;
-            const int nch = (d.rowptr[f + 1] - d.rowptr[f] + POSE_CHUNK - 1) / POSE_CHUNK;
+            const int nch = (d.erowptr[f + 1] - d.erowptr[f] + EDGE_CHUNK - 1) / EDGE_CHUNK;
             double s = 0.0;
             for (int c = 0; c < nch; c++) s += d.pose_part[((size_t)f * d.n_chunks_max + c) * 27 + q];
             if (q < 21) {
@@ -262,17 +297,18 @@ void ba_final_k(BaDev d, int n_pose_wg)
     if (tid == 0) (single ? d.robust_chi2 : d.chi_part + slice)[0] = s_r[0];
 }
 
+// sum of a slice-partial array in index order (robust chi2 / landmark part of computeScale)
 __global__ __launch_bounds__(256)
-void ba_final2_k(BaDev d, int n_slices)
+void ba_final2_k(const double* __restrict__ part, int n, double* __restrict__ out)
 {
     __shared__ double s_r[256];
     const int tid = threadIdx.x;
     double r = 0.0;
-    for (int i = tid; i < n_slices; i += 256) r += d.chi_part[i];
+    for (int i = tid; i < n; i += 256) r += part[i];
     s_r[tid] = r;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) { if (tid < o) s_r[tid] += s_r[tid + o]; __syncthreads(); }
-    if (tid == 0) d.robust_chi2[0] = s_r[0];
+    if (tid == 0) out[0] = s_r[0];
 }
 
 // ---- Schur complement on the device (BlockSolver::solve, block_solver.hpp:372-481)
@@ -284,7 +320,8 @@ void ba_schur_points_k(BaDev d)
     double M[9];
 #pragma unroll
     for (int q = 0; q < 9; q++) M[q] = d.Hll[(size_t)i * 9 + q];
-    M[0] += d.lambda; M[4] += d.lambda; M[8] += d.lambda;
+    const double lam = lam_point(d, i);
+    M[0] += lam; M[4] += lam; M[8] += lam;
     const double det = M[0] * (M[4] * M[8] - M[5] * M[7]) - M[1] * (M[3] * M[8] - M[5] * M[6]) + M[2] * (M[3] * M[7] - M[4] * M[6]);
     const double id = 1.0 / det;
     double I[9];
@@ -298,138 +335,204 @@ void ba_schur_points_k(BaDev d)
     for (int a = 0; a < 3; a++) d.db[(size_t)i * 3 + a] = I[a * 3] * bl[0] + I[a * 3 + 1] * bl[1] + I[a * 3 + 2] * bl[2];
 }
 
+// One workgroup per tile of SCHUR_TP consecutive points; the tile's blocks are read from HBM exactly once.  Points are
+// taken in groups of G (G * L <= SCHUR_GL): a thread stages one block B (6x3) of the group into LDS together with
+// B Dinv (computed on the way: Dinv is 3x3 per point) and a validity flag; then item (local pose pair (la <= lb), subset s)
+// adds (B Dinv)_{la} B_{lb}^T over its share of the group's points into 36 registers (g2o's own loop shape,
+// block_solver.hpp:381-432, with the point loop innermost).  The SCHUR_NSUB subsets of a pair sit in adjacent lanes and are
+// added by a 2-step butterfly at the end.  Lanes la < L also accumulate B (Dinv b_l): the tile's share of the reduced
+// right-hand side's coefficient, stored beside the diagonal pair (la, la).
+constexpr int SCHUR_GL = 96;       // (points x local poses) staged per group
+constexpr int SB_PITCH = 19;       // doubles per staged block: 18 values + validity; odd -> lanes spread over the LDS banks
 __global__ __launch_bounds__(256)
-void ba_schur_blocks_k(BaDev d)
+void ba_schur_tiles_k(BaDev d)
 {
-    const int k = blockIdx.x * 256 + threadIdx.x;
-    if (k >= d.nnzb) return;
-    const int i = d.col[k];
-    const double* B = d.Hpl_val + (size_t)k * 18;
-    const double* Di = d.Dinv + (size_t)i * 9;
-    const double* dbi = d.db + (size_t)i * 3;
+    __shared__ double s_B[SCHUR_GL * SB_PITCH], s_BD[SCHUR_GL * SB_PITCH];
+    __shared__ double s_cb[SCHUR_GL * 6];      // B (Dinv b_l) of the staged blocks
+    __shared__ double s_coef[SCHUR_LMAX * 6];  // running coefficient sums per local pose
+    const int tile = blockIdx.x, tid = threadIdx.x;
+    const int L = d.tile_pose_ptr[tile + 1] - d.tile_pose_ptr[tile];
+    if (L == 0) return;
+    const int npairs = L * (L + 1) / 2;
+    const int32_t* tb = d.tile_blk + d.tile_blk_ptr[tile];
+    const int i0 = tile * SCHUR_TP, np = min(SCHUR_TP, d.n_points - i0);
+    double* out = d.tile_part + (size_t)d.tile_out_ptr[tile] * 36;
+    double* cout = d.tile_coef + (size_t)d.tile_out_ptr[tile] * 6;
+    const int G = max(1, SCHUR_GL / L);
+    const int s = tid & (SCHUR_NSUB - 1);
+    const int npass = (npairs * SCHUR_NSUB + 255) / 256;       // pair passes (1 for L <= 10); wider tiles re-stage per pass
+    for (int idx = tid; idx < L * 6; idx += 256) s_coef[idx] = 0.0;
+    for (int pass = 0; pass < npass; pass++) {
+        const int p = tid / SCHUR_NSUB + pass * (256 / SCHUR_NSUB);
+        int la = 0, lb = 0;
+        if (p < npairs) { int rem = p; while (rem >= L - la) { rem -= L - la; la++; } lb = la + rem; }
+        double acc[36];
 #pragma unroll
-    for (int a = 0; a < 6; a++) {
+        for (int q = 0; q < 36; q++) acc[q] = 0.0;
+        for (int g0 = 0; g0 < np; g0 += G) {
+            const int gc = min(G, np - g0);
+            __syncthreads();   // the previous group's readers are done
+            for (int it = tid; it < gc * L; it += 256) {
+                // consecutive lanes take consecutive points of one local pose: their blocks are consecutive in the pose's row
+                const int lq = it / gc, pi = it - lq * gc;
+                const int idx = pi * L + lq;
+                const int k = tb[(g0 + pi) * L + lq];
+                double* sb = s_B + idx * SB_PITCH; double* sbd = s_BD + idx * SB_PITCH;
+                sb[18] = k >= 0 ? 1.0 : 0.0;
+                if (k >= 0) {
+                    const double2* src = reinterpret_cast<const double2*>(d.Hpl_val + (size_t)k * 18);
+                    const double* Di = d.Dinv + (size_t)(i0 + g0 + pi) * 9;
+                    const double* dbi = d.db + (size_t)(i0 + g0 + pi) * 3;
 #pragma unroll
-        for (int c = 0; c < 3; c++) d.BD[(size_t)k * 18 + a * 3 + c] = B[a * 3] * Di[c] + B[a * 3 + 1] * Di[3 + c] + B[a * 3 + 2] * Di[6 + c];
-        d.cblk[(size_t)k * 6 + a] = B[a * 3] * dbi[0] + B[a * 3 + 1] * dbi[1] + B[a * 3 + 2] * dbi[2];
-    }
-}
-
-// grid (chunk, pair): pair p <-> (j1 <= j2); lanes walk the blocks of pose row j1, look up the block of (j2, same point)
-__global__ __launch_bounds__(POSE_CHUNK)
-void ba_schur_pairs_k(BaDev d)
-{
-    const int chunk = blockIdx.x, tid = threadIdx.x;
-    int j1 = 0, rem = blockIdx.y; // unpack the upper-triangle pair index
-    while (rem >= d.n_free - j1) { rem -= d.n_free - j1; j1++; }
-    const int j2 = j1 + rem;
-    const int k0 = d.rowptr[j1], k1 = d.rowptr[j1 + 1];
-    if (k0 + chunk * POSE_CHUNK >= k1) return;
-    const int k = k0 + chunk * POSE_CHUNK + tid;
-    __shared__ double s_red[42 * POSE_CHUNK];
-    double v[42];
+                    for (int q = 0; q < 9; q++) { const double2 v2 = src[q]; sb[2 * q] = v2.x; sb[2 * q + 1] = v2.y; }
+                    const double D0 = Di[0], D1 = Di[1], D2 = Di[2], D3 = Di[3], D4 = Di[4], D5 = Di[5], D6 = Di[6], D7 = Di[7], D8 = Di[8];
+                    const double e0 = dbi[0], e1 = dbi[1], e2 = dbi[2];
 #pragma unroll
-    for (int q = 0; q < 42; q++) v[q] = 0.0;
-    if (k < k1) {
-        const int i = d.col[k];
-        const int k2 = d.blk_of[(size_t)j2 * d.n_points + i];
-        if (k2 >= 0) {
-            const double* BDk = d.BD + (size_t)k * 18;
-            const double* Bj = d.Hpl_val + (size_t)k2 * 18;
+                    for (int a = 0; a < 6; a++) {
+                        const double b0 = sb[a * 3], b1 = sb[a * 3 + 1], b2 = sb[a * 3 + 2];
+                        sbd[a * 3] = b0 * D0 + b1 * D3 + b2 * D6; sbd[a * 3 + 1] = b0 * D1 + b1 * D4 + b2 * D7; sbd[a * 3 + 2] = b0 * D2 + b1 * D5 + b2 * D8;
+                        if (pass == 0) s_cb[idx * 6 + a] = b0 * e0 + b1 * e1 + b2 * e2;
+                    }
+                }
+            }
+            __syncthreads();
+            if (p < npairs)
+                for (int pi = s; pi < gc; pi += SCHUR_NSUB) {
+                    const double* a_ = s_BD + (pi * L + la) * SB_PITCH;
+                    const double* b_ = s_B + (pi * L + lb) * SB_PITCH;
+                    if (s_B[(pi * L + la) * SB_PITCH + 18] == 0.0 || b_[18] == 0.0) continue;
+                    double bb[18];
 #pragma unroll
-            for (int a = 0; a < 6; a++)
+                    for (int q = 0; q < 18; q++) bb[q] = b_[q];
 #pragma unroll
-                for (int c = 0; c < 6; c++) v[a * 6 + c] = BDk[a * 3] * Bj[c * 3] + BDk[a * 3 + 1] * Bj[c * 3 + 1] + BDk[a * 3 + 2] * Bj[c * 3 + 2];
+                    for (int a = 0; a < 6; a++) {
+                        const double a0 = a_[a * 3], a1 = a_[a * 3 + 1], a2 = a_[a * 3 + 2];
+#pragma unroll
+                        for (int c = 0; c < 6; c++) acc[a * 6 + c] += a0 * bb[c * 3] + a1 * bb[c * 3 + 1] + a2 * bb[c * 3 + 2];
+                    }
+                }
+            if (pass == 0 && tid < L * 6) {   // coefficient of local pose tid / 6, component tid % 6: the group's points in order
+                const int lq = tid / 6, a = tid - 6 * lq;
+                double t = s_coef[tid];
+                for (int pi = 0; pi < gc; pi++)
+                    if (s_B[(pi * L + lq) * SB_PITCH + 18] != 0.0) t += s_cb[(pi * L + lq) * 6 + a];
+                s_coef[tid] = t;
+            }
         }
-        if (j1 == j2)
 #pragma unroll
-            for (int a = 0; a < 6; a++) v[36 + a] = d.cblk[(size_t)k * 6 + a];
+        for (int o = SCHUR_NSUB / 2; o > 0; o >>= 1)
+#pragma unroll
+            for (int q = 0; q < 36; q++) acc[q] += __shfl_xor(acc[q], o);
+        if (s == 0 && p < npairs)
+#pragma unroll
+            for (int q = 0; q < 36; q++) out[(size_t)p * 36 + q] = acc[q];
     }
-#pragma unroll
-    for (int q = 0; q < 42; q++) s_red[q * POSE_CHUNK + tid] = v[q];
     __syncthreads();
-    for (int o = POSE_CHUNK / 2; o > 0; o >>= 1) {
-        if (tid < o)
-#pragma unroll
-            for (int q = 0; q < 42; q++) s_red[q * POSE_CHUNK + tid] += s_red[q * POSE_CHUNK + tid + o];
-        __syncthreads();
+    for (int idx = tid; idx < L * 6; idx += 256) {
+        const int lq = idx / 6;
+        int pd = 0;   // index of the diagonal pair (lq, lq) in the tile's upper-triangle order
+        for (int a = 0; a < lq; a++) pd += L - a;
+        cout[(size_t)pd * 6 + (idx - 6 * lq)] = s_coef[idx];
     }
-    if (tid < 36) d.pair_part[((size_t)blockIdx.y * d.n_chunks_max + chunk) * 36 + tid] = s_red[tid * POSE_CHUNK];
-    else if (tid < 42 && j1 == j2) d.coef_part[((size_t)j1 * d.n_chunks_max + chunk) * 6 + (tid - 36)] = s_red[tid * POSE_CHUNK];
 }
 
+// S (zeroed by the caller) <- one 6x6 block per global pose pair that shares a point; b_s
+constexpr int FIN_SPLIT = 4;   // lanes per output element: partials q = r, r + 4, ..., then a fixed 2-step butterfly
 __global__ __launch_bounds__(256)
 void ba_schur_final_k(BaDev d)
 {
     const int np6 = 6 * d.n_free;
-    const int npairs = d.n_free * (d.n_free + 1) / 2;
-    for (int t = blockIdx.x * 256 + threadIdx.x; t < npairs * 36; t += gridDim.x * 256) {
-        const int p = t / 36, e = t % 36, a = e / 6, c = e % 6;
-        int j1 = 0, rem = p;
-        while (rem >= d.n_free - j1) { rem -= d.n_free - j1; j1++; }
-        const int j2 = j1 + rem;
-        const int nch = (d.rowptr[j1 + 1] - d.rowptr[j1] + POSE_CHUNK - 1) / POSE_CHUNK;
+    const long long n_el = (long long)d.n_gpairs * 36;
+    const long long n_thr = (n_el * FIN_SPLIT + 255) / 256 * 256;
+    for (long long t0 = (long long)blockIdx.x * 256 + threadIdx.x; t0 < n_thr; t0 += (long long)gridDim.x * 256) {
+        const long long t = t0 / FIN_SPLIT;
+        const int r = (int)(t0 % FIN_SPLIT);
         double sum = 0.0;
-        for (int ch = 0; ch < nch; ch++) sum += d.pair_part[((size_t)p * d.n_chunks_max + ch) * 36 + e];
-        double val = -sum;
-        if (j1 == j2) val += d.Hpp[(size_t)j1 * 36 + e] + (a == c ? d.lambda : 0.0);
-        d.S[(size_t)(6 * j1 + a) * np6 + 6 * j2 + c] = val;
-        if (j1 != j2) d.S[(size_t)(6 * j2 + c) * np6 + 6 * j1 + a] = val;
+        int g = 0, e = 0;
+        if (t < n_el) {
+            g = (int)(t / 36); e = (int)(t % 36);
+            for (int q = d.gpair_ptr[g] + r; q < d.gpair_ptr[g + 1]; q += FIN_SPLIT) sum += d.tile_part[(size_t)d.gpair_src[q] * 36 + e];   // tile order
+        }
+#pragma unroll
+        for (int o = FIN_SPLIT / 2; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+        if (t < n_el && r == 0) {
+            const int a = e / 6, c = e % 6;
+            const int j1 = d.gpair_j[2 * g], j2 = d.gpair_j[2 * g + 1];
+            double val = -sum;
+            if (j1 == j2) val += d.Hpp[(size_t)j1 * 36 + e] + (a == c ? lam_pose(d, j1) : 0.0);
+            d.S[(size_t)(6 * j1 + a) * np6 + 6 * j2 + c] = val;
+            if (j1 != j2) d.S[(size_t)(6 * j2 + c) * np6 + 6 * j1 + a] = val;
+        }
     }
+    // b_s = b_p - sum_i B_ji (Dinv b_l)_i: the tile shares stored beside the diagonal pairs, in tile order
     for (int t = blockIdx.x * 256 + threadIdx.x; t < np6; t += gridDim.x * 256) {
         const int j = t / 6, a = t % 6;
-        const int nch = (d.rowptr[j + 1] - d.rowptr[j] + POSE_CHUNK - 1) / POSE_CHUNK;
+        const int g = d.gdiag[j];
         double sum = 0.0;
-        for (int ch = 0; ch < nch; ch++) sum += d.coef_part[((size_t)j * d.n_chunks_max + ch) * 6 + a];
+        if (g >= 0)
+            for (int q = d.gpair_ptr[g]; q < d.gpair_ptr[g + 1]; q++) sum += d.tile_coef[(size_t)d.gpair_src[q] * 6 + a];
         d.bs[t] = d.b[t] - sum;
     }
 }
 
-// x_l = Dinv (b_l - Hpl^T x_p); optional X += x_l; per-block partial of x_l . (lambda x_l + b_l) for computeScale
+// x_l = Dinv (b_l - Hpl^T x_p); optional X += x_l; per point x_l . (lambda x_l + b_l) for computeScale
 __global__ __launch_bounds__(256)
 void ba_backsub_k(BaDev d, int apply, double* points_rw)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x, tid = threadIdx.x;
-    double sc = 0.0;
-    if (i < d.n_points) {
-        const double* bl = d.b + 6 * d.n_free + 3 * (size_t)i;
-        double cl[3] = { bl[0], bl[1], bl[2] };
-        for (int q = d.pt_ptr[i]; q < d.pt_ptr[i + 1]; q++) {
-            const int e = d.pt_edge[q];
-            const int sl = d.slot[e];
-            if (sl < 0) continue;
-            const double* B = d.Hpl_val + (size_t)sl * 18;
-            const double* xp = d.x + 6 * d.fidx[d.edge_pose[e]];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= d.n_points) return;
+    const double* bl = d.b + 6 * d.n_free + 3 * (size_t)i;
+    double cl[3] = { bl[0], bl[1], bl[2] };
+    for (int q = d.pt_ptr[i]; q < d.pt_ptr[i + 1]; q++) {
+        const int k = d.pt_k[q];
+        if (k >= d.nnzb) break;   // ascending: the rest belongs to fixed rows
+        const double* B = d.Hpl_val + (size_t)k * 18;
+        const double* xp = d.x + 6 * d.blk_row[k];
 #pragma unroll
-            for (int c = 0; c < 3; c++)
+        for (int c = 0; c < 3; c++)
 #pragma unroll
-                for (int a = 0; a < 6; a++) cl[c] -= B[a * 3 + c] * xp[a];
-        }
-        const double* Di = d.Dinv + (size_t)i * 9;
-        double xl[3];
-#pragma unroll
-        for (int a = 0; a < 3; a++) xl[a] = Di[a * 3] * cl[0] + Di[a * 3 + 1] * cl[1] + Di[a * 3 + 2] * cl[2];
-#pragma unroll
-        for (int a = 0; a < 3; a++) {
-            d.x[6 * d.n_free + 3 * (size_t)i + a] = xl[a];
-            sc += xl[a] * (d.lambda * xl[a] + bl[a]);
-            if (apply) points_rw[3 * (size_t)i + a] += xl[a];
-        }
+            for (int a = 0; a < 6; a++) cl[c] -= B[a * 3 + c] * xp[a];
     }
-    __shared__ double s_r[256];
-    s_r[tid] = sc;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) { if (tid < o) s_r[tid] += s_r[tid + o]; __syncthreads(); }
-    if (tid == 0) d.scale_part[blockIdx.x] = s_r[0];
+    const double* Di = d.Dinv + (size_t)i * 9;
+    const double lam = lam_point(d, i);
+    double sc = 0.0;
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        const double xl = Di[a * 3] * cl[0] + Di[a * 3 + 1] * cl[1] + Di[a * 3 + 2] * cl[2];
+        d.x[6 * d.n_free + 3 * (size_t)i + a] = xl;
+        sc += xl * (lam * xl + bl[a]);
+        if (apply) points_rw[3 * (size_t)i + a] += xl;
+    }
+    d.pt_scale[i] = sc;
 }
 
-__global__ void ba_scale_final_k(BaDev d, int nblocks)
+// fixed-shape slice sums of a per-point array (4096 points per workgroup)
+__global__ __launch_bounds__(256)
+void ba_slice_sum_k(const double* __restrict__ v, int n, double* __restrict__ part)
 {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        double s = 0.0;
-        for (int q = 0; q < nblocks; q++) s += d.scale_part[q];
-        d.scale_l[0] = s;
-    }
+    __shared__ double s_r[256];
+    const int tid = threadIdx.x, p0 = blockIdx.x * CHI_SLICE, p1 = min(n, p0 + CHI_SLICE);
+    double r = 0.0;
+    for (int i = p0 + tid; i < p1; i += 256) r += v[i];
+    s_r[tid] = r;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (tid < o) s_r[tid] += s_r[tid + o]; __syncthreads(); }
+    if (tid == 0) part[blockIdx.x] = s_r[0];
+}
+
+// one workgroup per window: robust chi2 (which = 0, from pt_rho) or the landmark part of computeScale (which = 1, from pt_scale)
+__global__ __launch_bounds__(256)
+void ba_window_sums_k(BaDev d, int which)
+{
+    __shared__ double s_r[256];
+    const int w = blockIdx.x, tid = threadIdx.x;
+    const double* v = which ? d.pt_scale : d.pt_rho;
+    double r = 0.0;
+    for (int q = d.win_pt_ptr[w] + tid; q < d.win_pt_ptr[w + 1]; q += 256) r += v[d.win_pt[q]];
+    s_r[tid] = r;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (tid < o) s_r[tid] += s_r[tid + o]; __syncthreads(); }
+    if (tid == 0) d.win_out[2 * w + which] = s_r[0];
 }
 
 } // namespace
@@ -437,10 +540,13 @@ __global__ void ba_scale_final_k(BaDev d, int nblocks)
 struct mslam_ba_plan {
     mslam_ctx* ctx = nullptr;
     void* arena = nullptr;
+    void* win_arena = nullptr;
     BaDev dev{};
     double* d_poses = nullptr; double* d_points = nullptr;
     int32_t* d_rowptr = nullptr; int32_t* d_col = nullptr;
+    double* d_lam = nullptr;                 // [max(1, n_windows)]
     std::vector<int32_t> h_rowptr, h_col;
+    std::vector<int32_t> h_row_pose;         // pose of a free row
     bool has_schur = false;
 };
 
@@ -475,100 +581,195 @@ int mslam_ba_plan_create(mslam_ctx* ctx, const mslam_ba_problem* p, mslam_ba_pla
     MSLAM_TRY(ba_validate(p));
     MSLAM_TRY(ctx_set_device(ctx));
     const int NP = p->n_poses, NL = p->n_points, E = p->n_edges;
-    std::vector<int32_t> fidx(NP), pt_ptr(NL + 1, 0), pt_edge(E), slot(E, -1);
+    std::vector<int32_t> fidx(NP);
     int nf = 0;
     for (int j = 0; j < NP; j++) fidx[j] = p->pose_fixed[j] ? -1 : nf++;
-    for (int e = 0; e < E; e++) pt_ptr[p->edge_point[e] + 1]++;
+    // rows: free poses 0..nf-1 (free-index order, also those without edges, so that row == free index), then the fixed
+    // poses that have edges
+    std::vector<int32_t> row_of_pose(NP, -1), row_pose;
+    for (int j = 0; j < NP; j++) if (fidx[j] >= 0) { row_of_pose[j] = (int)row_pose.size(); row_pose.push_back(j); }
+    {
+        std::vector<char> has(NP, 0);
+        for (int e = 0; e < E; e++) has[p->edge_pose[e]] = 1;
+        for (int j = 0; j < NP; j++) if (fidx[j] < 0 && has[j]) { row_of_pose[j] = (int)row_pose.size(); row_pose.push_back(j); }
+    }
+    const int R = (int)row_pose.size();
+    std::vector<int32_t> erowptr(R + 1, 0);
+    for (int e = 0; e < E; e++) erowptr[row_of_pose[p->edge_pose[e]] + 1]++;
+    for (int r = 0; r < R; r++) erowptr[r + 1] += erowptr[r];
+    const int nnzb = erowptr[nf];
+    std::vector<std::pair<int32_t, int32_t>> pe(E);   // (point, edge) per row, sorted
+    {
+        std::vector<int32_t> fill(R, 0);
+        for (int e = 0; e < E; e++) { const int r = row_of_pose[p->edge_pose[e]]; pe[erowptr[r] + fill[r]++] = { p->edge_point[e], e }; }
+    }
+    int max_row = 0;
+    for (int r = 0; r < R; r++) {
+        std::sort(pe.begin() + erowptr[r], pe.begin() + erowptr[r + 1]);
+        max_row = std::max(max_row, erowptr[r + 1] - erowptr[r]);
+        // two edges between the same pose and point would need one accumulated block (g2o adds them into one); this layout
+        // gives every edge its own block, so such graphs are refused instead of being solved wrongly
+        for (int k = erowptr[r] + 1; k < erowptr[r + 1]; k++)
+            if (pe[k].first == pe[k - 1].first) return MSLAM_ERR_INVALID;
+    }
+    std::vector<int2> rec(E);
+    std::vector<double2> obs_k(E);
+    std::vector<int32_t> col(std::max(nnzb, 1)), blk_row(std::max(nnzb, 1)), pt_ptr(NL + 1, 0), pt_k(E);
+    for (int r = 0; r < R; r++)
+        for (int k = erowptr[r]; k < erowptr[r + 1]; k++) {
+            rec[k] = make_int2(pe[k].first, pe[k].second);
+            obs_k[k] = make_double2(p->obs[2 * pe[k].second], p->obs[2 * pe[k].second + 1]);
+            if (k < nnzb) { col[k] = pe[k].first; blk_row[k] = r; }
+            pt_ptr[pe[k].first + 1]++;
+        }
     for (int i = 0; i < NL; i++) pt_ptr[i + 1] += pt_ptr[i];
     {
         std::vector<int32_t> fill(NL, 0);
-        for (int e = 0; e < E; e++) { int i = p->edge_point[e]; pt_edge[pt_ptr[i] + fill[i]++] = e; } // ascending edge id
+        for (int k = 0; k < E; k++) { const int i = rec[k].x; pt_k[pt_ptr[i] + fill[i]++] = k; }   // ascending k
     }
-    std::vector<int32_t> rowptr(nf + 1, 0);
-    for (int e = 0; e < E; e++) { int f = fidx[p->edge_pose[e]]; if (f >= 0) rowptr[f + 1]++; }
-    for (int f = 0; f < nf; f++) rowptr[f + 1] += rowptr[f];
-    const int nnzb = rowptr[nf];
-    std::vector<std::pair<int32_t, int32_t>> pe(nnzb);
-    {
-        std::vector<int32_t> fill(nf, 0);
-        for (int e = 0; e < E; e++) { int f = fidx[p->edge_pose[e]]; if (f >= 0) pe[rowptr[f] + fill[f]++] = { p->edge_point[e], e }; }
+    const int n_chunks_max = std::max(1, (max_row + EDGE_CHUNK - 1) / EDGE_CHUNK);
+
+    // ---- Schur tiles: local pose lists, dense point x local-pose block tables, partial offsets, global pair lists
+    const int n_tiles = (NL + SCHUR_TP - 1) / SCHUR_TP;
+    std::vector<int32_t> tile_pose_ptr(n_tiles + 1, 0), tile_pose, tile_blk_ptr(n_tiles + 1, 0), tile_blk;
+    std::vector<long long> tile_out_ptr(n_tiles + 1, 0);
+    bool want_schur = nf > 0 && nnzb > 0;
+    std::vector<int32_t> gpair_j, gpair_ptr;
+    std::vector<long long> gpair_src;
+    if (want_schur) {
+        std::vector<int32_t> loc(nf, -1);
+        for (int t = 0; t < n_tiles && want_schur; t++) {
+            const int i0 = t * SCHUR_TP, i1 = std::min(NL, i0 + SCHUR_TP);
+            std::vector<int32_t> lp;
+            for (int i = i0; i < i1; i++)
+                for (int q = pt_ptr[i]; q < pt_ptr[i + 1]; q++) { const int k = pt_k[q]; if (k < nnzb) lp.push_back(blk_row[k]); }
+            std::sort(lp.begin(), lp.end());
+            lp.erase(std::unique(lp.begin(), lp.end()), lp.end());
+            const int L = (int)lp.size();
+            if (L > SCHUR_LMAX) { want_schur = false; break; }   // a tile that sees too many poses: host Schur (MSLAM_ERR_CAPACITY)
+            for (int a = 0; a < L; a++) loc[lp[a]] = a;
+            const size_t base = tile_blk.size();
+            tile_blk.resize(base + (size_t)SCHUR_TP * L, -1);
+            for (int i = i0; i < i1; i++)
+                for (int q = pt_ptr[i]; q < pt_ptr[i + 1]; q++) { const int k = pt_k[q]; if (k < nnzb) tile_blk[base + (size_t)(i - i0) * L + loc[blk_row[k]]] = k; }
+            tile_pose.insert(tile_pose.end(), lp.begin(), lp.end());
+            tile_pose_ptr[t + 1] = (int)tile_pose.size();
+            if (tile_blk.size() > (size_t)0x7FFFFFFF) { want_schur = false; break; }
+            tile_blk_ptr[t + 1] = (int)tile_blk.size();
+            tile_out_ptr[t + 1] = tile_out_ptr[t] + (long long)L * (L + 1) / 2;
+        }
     }
-    int max_row = 0;
-    for (int f = 0; f < nf; f++) {
-        std::sort(pe.begin() + rowptr[f], pe.begin() + rowptr[f + 1]);
-        max_row = std::max(max_row, rowptr[f + 1] - rowptr[f]);
+    if (want_schur) {
+        // global pairs (j1 <= j2) <- (tile, local pair) partials, in tile order
+        struct Src { int32_t j1, j2; long long idx; };
+        std::vector<Src> src;
+        src.reserve((size_t)tile_out_ptr[n_tiles]);
+        for (int t = 0; t < n_tiles; t++) {
+            const int p0 = tile_pose_ptr[t], L = tile_pose_ptr[t + 1] - p0;
+            long long q = tile_out_ptr[t];
+            for (int a = 0; a < L; a++)
+                for (int b2 = a; b2 < L; b2++) src.push_back({ tile_pose[p0 + a], tile_pose[p0 + b2], q++ });
+        }
+        std::stable_sort(src.begin(), src.end(), [](const Src& a, const Src& b2) { return a.j1 != b2.j1 ? a.j1 < b2.j1 : a.j2 < b2.j2; });
+        for (size_t q = 0; q < src.size(); q++) {
+            if (q == 0 || src[q].j1 != src[q - 1].j1 || src[q].j2 != src[q - 1].j2) { gpair_j.push_back(src[q].j1); gpair_j.push_back(src[q].j2); gpair_ptr.push_back((int32_t)q); }
+            gpair_src.push_back(src[q].idx);
+        }
+        gpair_ptr.push_back((int32_t)src.size());
+        // free poses without any block still need their diagonal S block (Hpp = 0 there: a singular system, as in g2o)
+        if (src.size() > (size_t)0x7FFFFFF0) want_schur = false;
     }
-    std::vector<int32_t> col(nnzb), blk_edge(nnzb);
-    for (int k = 0; k < nnzb; k++) { col[k] = pe[k].first; blk_edge[k] = pe[k].second; slot[pe[k].second] = k; }
-    const int n_chunks_max = std::max(1, (max_row + POSE_CHUNK - 1) / POSE_CHUNK);
+    const int n_gpairs = want_schur ? (int)gpair_j.size() / 2 : 0;
+    std::vector<int32_t> gdiag(std::max(nf, 1), -1);
+    for (int g = 0; g < n_gpairs; g++) if (gpair_j[2 * g] == gpair_j[2 * g + 1]) gdiag[gpair_j[2 * g]] = g;
 
     mslam_ba_plan* pl = new mslam_ba_plan();
     pl->ctx = ctx;
     size_t bytes = 0;
     auto reserve = [&](size_t n) { bytes = align_up(bytes, 256); size_t o = bytes; bytes += n; return o; };
     const size_t o_poses = reserve(sizeof(double) * 7 * NP), o_points = reserve(sizeof(double) * 3 * NL),
-                 o_ep = reserve(sizeof(int32_t) * E), o_el = reserve(sizeof(int32_t) * E), o_obs = reserve(sizeof(double) * 2 * E),
-                 o_info = reserve(sizeof(double) * E), o_intr = reserve(sizeof(double) * 4 * NP), o_fidx = reserve(sizeof(int32_t) * NP),
-                 o_ptp = reserve(sizeof(int32_t) * (NL + 1)), o_pte = reserve(sizeof(int32_t) * E),
-                 o_row = reserve(sizeof(int32_t) * (nf + 1)), o_col = reserve(sizeof(int32_t) * std::max(nnzb, 1)),
-                 o_be = reserve(sizeof(int32_t) * std::max(nnzb, 1)), o_slot = reserve(sizeof(int32_t) * E),
+                 o_ep = reserve(sizeof(int32_t) * E), o_info = reserve(sizeof(double) * E), o_intr = reserve(sizeof(double) * 4 * NP),
+                 o_fidx = reserve(sizeof(int32_t) * NP), o_erow = reserve(sizeof(int32_t) * (R + 1)), o_rowp = reserve(sizeof(int32_t) * R),
+                 o_rec = reserve(sizeof(int2) * E), o_obs = reserve(sizeof(double2) * E),
+                 o_ptp = reserve(sizeof(int32_t) * (NL + 1)), o_ptk = reserve(sizeof(int32_t) * E),
+                 o_col = reserve(sizeof(int32_t) * std::max(nnzb, 1)), o_brow = reserve(sizeof(int32_t) * std::max(nnzb, 1)),
                  o_err = reserve(sizeof(double) * 2 * E), o_chi = reserve(sizeof(double) * E), o_rho = reserve(sizeof(double) * E),
                  o_hpp = reserve(sizeof(double) * 36 * std::max(nf, 1)), o_hll = reserve(sizeof(double) * 9 * NL),
                  o_hpl = reserve(sizeof(double) * 18 * std::max(nnzb, 1)), o_b = reserve(sizeof(double) * (6 * nf + 3 * NL)),
-                 o_ptr = reserve(sizeof(double) * NL), o_chp = reserve(sizeof(double) * ((size_t)NL / 4096 + 1)), o_pp = reserve(sizeof(double) * 27 * (size_t)std::max(nf, 1) * n_chunks_max),
-                 o_rc = reserve(sizeof(double));
-    // Schur scratch (dense pose-row x point lookup: fine for local-BA sizes; skipped when it would be huge)
-    const bool want_schur = (size_t)nf * NL <= ((size_t)1 << 26) && nf > 0 && nnzb > 0;
-    const int npairs = nf * (nf + 1) / 2;
-    size_t o_blk = 0, o_dinv = 0, o_db = 0, o_bd = 0, o_cb = 0, o_pp2 = 0, o_cp = 0, o_S = 0, o_bs = 0, o_x = 0, o_bk = 0, o_sp = 0, o_sl = 0;
+                 o_pts = reserve(sizeof(double) * 10 * (size_t)E),
+                 o_ptr = reserve(sizeof(double) * NL), o_chp = reserve(sizeof(double) * ((size_t)NL / CHI_SLICE + 1)),
+                 o_pp = reserve(sizeof(double) * 27 * (size_t)std::max(nf, 1) * n_chunks_max), o_rc = reserve(sizeof(double)),
+                 o_lam = reserve(sizeof(double));
+    size_t o_tpp = 0, o_tp = 0, o_tbp = 0, o_tb = 0, o_top = 0, o_gj = 0, o_gp = 0, o_gs = 0, o_part = 0, o_dinv = 0, o_db = 0, o_gd = 0, o_tc = 0,
+           o_S = 0, o_bs = 0, o_x = 0, o_bk = 0, o_psc = 0, o_sp = 0, o_sl = 0;
     if (want_schur) {
-        o_blk = reserve(sizeof(int32_t) * (size_t)nf * NL); o_dinv = reserve(sizeof(double) * 9 * NL); o_db = reserve(sizeof(double) * 3 * NL);
-        o_bd = reserve(sizeof(double) * 18 * nnzb); o_cb = reserve(sizeof(double) * 6 * nnzb);
-        o_pp2 = reserve(sizeof(double) * 36 * (size_t)npairs * n_chunks_max); o_cp = reserve(sizeof(double) * 6 * (size_t)nf * n_chunks_max);
+        o_tpp = reserve(sizeof(int32_t) * (n_tiles + 1)); o_tp = reserve(sizeof(int32_t) * std::max<size_t>(tile_pose.size(), 1));
+        o_tbp = reserve(sizeof(int32_t) * (n_tiles + 1)); o_tb = reserve(sizeof(int32_t) * std::max<size_t>(tile_blk.size(), 1));
+        o_top = reserve(sizeof(long long) * (n_tiles + 1));
+        o_gj = reserve(sizeof(int32_t) * 2 * std::max(n_gpairs, 1)); o_gp = reserve(sizeof(int32_t) * (n_gpairs + 1));
+        o_gs = reserve(sizeof(long long) * std::max<size_t>(gpair_src.size(), 1));
+        o_part = reserve(sizeof(double) * 36 * (size_t)std::max<long long>(tile_out_ptr[n_tiles], 1));
+        o_dinv = reserve(sizeof(double) * 9 * NL); o_db = reserve(sizeof(double) * 3 * NL);
+        o_gd = reserve(sizeof(int32_t) * std::max(nf, 1)); o_tc = reserve(sizeof(double) * 6 * (size_t)std::max<long long>(tile_out_ptr[n_tiles], 1));
         o_S = reserve(sizeof(double) * 36 * (size_t)nf * nf); o_bs = reserve(sizeof(double) * 6 * nf);
         o_x = reserve(sizeof(double) * (6 * nf + 3 * NL)); o_bk = reserve(sizeof(double) * 3 * NL);
-        o_sp = reserve(sizeof(double) * ((NL + 255) / 256)); o_sl = reserve(sizeof(double));
+        o_psc = reserve(sizeof(double) * NL); o_sp = reserve(sizeof(double) * ((size_t)NL / CHI_SLICE + 1)); o_sl = reserve(sizeof(double));
     }
     hipError_t he = hipMalloc(&pl->arena, bytes);
     if (he != hipSuccess) { ctx->last_hip_error = std::string("hipMalloc(ba plan): ") + hipGetErrorString(he); delete pl; return MSLAM_ERR_HIP; }
     char* base = (char*)pl->arena;
     hipStream_t st = ctx->stream;
     auto up = [&](size_t off, const void* src, size_t n) { return n ? hipMemcpyAsync(base + off, src, n, hipMemcpyHostToDevice, st) : hipSuccess; };
-    hipError_t errs[] = {
+    const double lam0 = 0.0;
+    std::vector<hipError_t> errs = {
         up(o_poses, p->poses, sizeof(double) * 7 * NP), up(o_points, p->points, sizeof(double) * 3 * NL),
-        up(o_ep, p->edge_pose, sizeof(int32_t) * E), up(o_el, p->edge_point, sizeof(int32_t) * E),
-        up(o_obs, p->obs, sizeof(double) * 2 * E), up(o_info, p->info, sizeof(double) * E), up(o_intr, p->intr, sizeof(double) * 4 * NP),
-        up(o_fidx, fidx.data(), sizeof(int32_t) * NP), up(o_ptp, pt_ptr.data(), sizeof(int32_t) * (NL + 1)),
-        up(o_pte, pt_edge.data(), sizeof(int32_t) * E), up(o_row, rowptr.data(), sizeof(int32_t) * (nf + 1)),
-        up(o_col, col.data(), sizeof(int32_t) * nnzb), up(o_be, blk_edge.data(), sizeof(int32_t) * nnzb),
-        up(o_slot, slot.data(), sizeof(int32_t) * E), hipStreamSynchronize(st) };
+        up(o_ep, p->edge_pose, sizeof(int32_t) * E), up(o_info, p->info, sizeof(double) * E), up(o_intr, p->intr, sizeof(double) * 4 * NP),
+        up(o_fidx, fidx.data(), sizeof(int32_t) * NP), up(o_erow, erowptr.data(), sizeof(int32_t) * (R + 1)),
+        up(o_rowp, row_pose.data(), sizeof(int32_t) * R), up(o_rec, rec.data(), sizeof(int2) * E), up(o_obs, obs_k.data(), sizeof(double2) * E),
+        up(o_ptp, pt_ptr.data(), sizeof(int32_t) * (NL + 1)), up(o_ptk, pt_k.data(), sizeof(int32_t) * E),
+        up(o_col, col.data(), sizeof(int32_t) * nnzb), up(o_brow, blk_row.data(), sizeof(int32_t) * nnzb), up(o_lam, &lam0, sizeof(double)) };
+    if (want_schur) {
+        errs.push_back(up(o_tpp, tile_pose_ptr.data(), sizeof(int32_t) * (n_tiles + 1)));
+        errs.push_back(up(o_tp, tile_pose.data(), sizeof(int32_t) * tile_pose.size()));
+        errs.push_back(up(o_tbp, tile_blk_ptr.data(), sizeof(int32_t) * (n_tiles + 1)));
+        errs.push_back(up(o_tb, tile_blk.data(), sizeof(int32_t) * tile_blk.size()));
+        errs.push_back(up(o_top, tile_out_ptr.data(), sizeof(long long) * (n_tiles + 1)));
+        errs.push_back(up(o_gj, gpair_j.data(), sizeof(int32_t) * gpair_j.size()));
+        errs.push_back(up(o_gp, gpair_ptr.data(), sizeof(int32_t) * gpair_ptr.size()));
+        errs.push_back(up(o_gs, gpair_src.data(), sizeof(long long) * gpair_src.size()));
+        errs.push_back(up(o_gd, gdiag.data(), sizeof(int32_t) * gdiag.size()));
+    }
+    errs.push_back(hipStreamSynchronize(st));
     for (hipError_t e : errs)
         if (e != hipSuccess) { ctx->last_hip_error = std::string("ba plan upload: ") + hipGetErrorString(e); (void)hipFree(pl->arena); delete pl; return MSLAM_ERR_HIP; }
     BaDev& d = pl->dev;
-    d.n_poses = NP; d.n_points = NL; d.n_edges = E; d.n_free = nf; d.nnzb = nnzb; d.n_chunks_max = n_chunks_max;
+    d.n_poses = NP; d.n_points = NL; d.n_edges = E; d.n_free = nf; d.nnzb = nnzb; d.n_rows = R; d.n_chunks_max = n_chunks_max;
     d.huber_delta = p->huber_delta; d.dsqr = (float)(p->huber_delta * p->huber_delta); // RobustKernelHuber: float dsqr
     d.poses = (double*)(base + o_poses); d.points = (double*)(base + o_points);
-    d.edge_pose = (int32_t*)(base + o_ep); d.edge_point = (int32_t*)(base + o_el); d.obs = (double*)(base + o_obs);
-    d.info = (double*)(base + o_info); d.intr = (double*)(base + o_intr); d.fidx = (int32_t*)(base + o_fidx);
-    d.pt_ptr = (int32_t*)(base + o_ptp); d.pt_edge = (int32_t*)(base + o_pte);
-    d.rowptr = (int32_t*)(base + o_row); d.blk_edge = (int32_t*)(base + o_be); d.slot = (int32_t*)(base + o_slot);
+    d.edge_pose = (int32_t*)(base + o_ep); d.info = (double*)(base + o_info); d.intr = (double*)(base + o_intr); d.fidx = (int32_t*)(base + o_fidx);
+    d.erowptr = (int32_t*)(base + o_erow); d.row_pose = (int32_t*)(base + o_rowp); d.rec = (int2*)(base + o_rec); d.obs_k = (double2*)(base + o_obs);
+    d.pt_ptr = (int32_t*)(base + o_ptp); d.pt_k = (int32_t*)(base + o_ptk); d.blk_row = (int32_t*)(base + o_brow);
     d.err = (double*)(base + o_err); d.chi2 = (double*)(base + o_chi); d.rho1 = (double*)(base + o_rho);
     d.Hpp = (double*)(base + o_hpp); d.Hll = (double*)(base + o_hll); d.Hpl_val = (double*)(base + o_hpl); d.b = (double*)(base + o_b);
+    d.ptside = (double*)(base + o_pts);
     d.pt_rho = (double*)(base + o_ptr); d.chi_part = (double*)(base + o_chp); d.pose_part = (double*)(base + o_pp); d.robust_chi2 = (double*)(base + o_rc);
     pl->d_poses = (double*)(base + o_poses); pl->d_points = (double*)(base + o_points);
-    pl->d_rowptr = (int32_t*)(base + o_row); pl->d_col = (int32_t*)(base + o_col);
-    pl->h_rowptr = rowptr; pl->h_col = col;
+    pl->d_rowptr = (int32_t*)(base + o_erow); pl->d_col = (int32_t*)(base + o_col);   // free rows come first: erowptr[0..nf] IS the block-CSR row pointer
+    pl->h_rowptr.assign(erowptr.begin(), erowptr.begin() + nf + 1);
+    pl->h_col.assign(col.begin(), col.begin() + nnzb);
+    pl->h_row_pose.assign(row_pose.begin(), row_pose.begin() + nf);
     d.col = (int32_t*)(base + o_col);
+    pl->d_lam = (double*)(base + o_lam);
+    d.n_windows = 1; d.pose_win = nullptr; d.point_win = nullptr; d.win_pt_ptr = nullptr; d.win_pt = nullptr; d.lam_w = pl->d_lam; d.win_out = nullptr;
     if (want_schur) {
-        std::vector<int32_t> blk_of((size_t)nf * NL, -1);
-        for (int f = 0; f < nf; f++)
-            for (int k = rowptr[f]; k < rowptr[f + 1]; k++) blk_of[(size_t)f * NL + col[k]] = k;
-        hipError_t e2 = hipMemcpy(base + o_blk, blk_of.data(), sizeof(int32_t) * blk_of.size(), hipMemcpyHostToDevice);
-        if (e2 != hipSuccess) { ctx->last_hip_error = std::string("ba plan upload: ") + hipGetErrorString(e2); (void)hipFree(pl->arena); delete pl; return MSLAM_ERR_HIP; }
-        d.blk_of = (int32_t*)(base + o_blk); d.Dinv = (double*)(base + o_dinv); d.db = (double*)(base + o_db); d.BD = (double*)(base + o_bd);
-        d.cblk = (double*)(base + o_cb); d.pair_part = (double*)(base + o_pp2); d.coef_part = (double*)(base + o_cp);
+        d.n_tiles = n_tiles; d.n_tile_pairs = tile_out_ptr[n_tiles];
+        d.tile_pose_ptr = (int32_t*)(base + o_tpp); d.tile_pose = (int32_t*)(base + o_tp);
+        d.tile_blk_ptr = (int32_t*)(base + o_tbp); d.tile_blk = (int32_t*)(base + o_tb); d.tile_out_ptr = (long long*)(base + o_top);
+        d.n_gpairs = n_gpairs; d.gpair_j = (int32_t*)(base + o_gj); d.gpair_ptr = (int32_t*)(base + o_gp); d.gpair_src = (long long*)(base + o_gs);
+        d.tile_part = (double*)(base + o_part);
+        d.Dinv = (double*)(base + o_dinv); d.db = (double*)(base + o_db); d.gdiag = (int32_t*)(base + o_gd); d.tile_coef = (double*)(base + o_tc);
         d.S = (double*)(base + o_S); d.bs = (double*)(base + o_bs); d.x = (double*)(base + o_x); d.points_bk = (double*)(base + o_bk);
-        d.scale_part = (double*)(base + o_sp); d.scale_l = (double*)(base + o_sl);
+        d.pt_scale = (double*)(base + o_psc); d.scale_part = (double*)(base + o_sp); d.scale_l = (double*)(base + o_sl);
         pl->has_schur = true;
     }
     *out = pl;
@@ -580,6 +781,7 @@ void mslam_ba_plan_destroy(mslam_ba_plan* pl)
     if (!pl) return;
     (void)hipSetDevice(pl->ctx->device);
     (void)hipStreamSynchronize(pl->ctx->stream);
+    if (pl->win_arena) (void)hipFree(pl->win_arena);
     if (pl->arena) (void)hipFree(pl->arena);
     delete pl;
 }
@@ -619,24 +821,60 @@ int mslam_ba_plan_set_robust(mslam_ba_plan* pl, const double* info, double huber
     return MSLAM_OK;
 }
 
+int mslam_ba_plan_set_windows(mslam_ba_plan* pl, const int32_t* pose_window, const int32_t* point_window, int n_windows)
+{
+    if (!pl || !pose_window || !point_window || n_windows < 1) return MSLAM_ERR_INVALID;
+    mslam_ctx* ctx = pl->ctx;
+    MSLAM_TRY(ctx_set_device(ctx));
+    BaDev& d = pl->dev;
+    const int nf = d.n_free, NL = d.n_points;
+    std::vector<int32_t> pw(std::max(nf, 1), 0), ptr(n_windows + 1, 0), lst(NL);
+    for (int f = 0; f < nf; f++) {
+        const int w = pose_window[pl->h_row_pose[f]];
+        if (w < 0 || w >= n_windows) return MSLAM_ERR_INVALID;
+        pw[f] = w;
+    }
+    for (int i = 0; i < NL; i++) { if (point_window[i] < 0 || point_window[i] >= n_windows) return MSLAM_ERR_INVALID; ptr[point_window[i] + 1]++; }
+    for (int w = 0; w < n_windows; w++) ptr[w + 1] += ptr[w];
+    {
+        std::vector<int32_t> fill(n_windows, 0);
+        for (int i = 0; i < NL; i++) lst[ptr[point_window[i]] + fill[point_window[i]]++] = i;
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (pl->win_arena) { HIP_TRY(ctx, hipFree(pl->win_arena)); pl->win_arena = nullptr; }
+    size_t bytes = 0;
+    auto reserve = [&](size_t n) { bytes = align_up(bytes, 256); size_t o = bytes; bytes += n; return o; };
+    const size_t o_pw = reserve(sizeof(int32_t) * std::max(nf, 1)), o_qw = reserve(sizeof(int32_t) * NL), o_ptr = reserve(sizeof(int32_t) * (n_windows + 1)),
+                 o_lst = reserve(sizeof(int32_t) * NL), o_lam = reserve(sizeof(double) * n_windows), o_out = reserve(sizeof(double) * 2 * n_windows);
+    HIP_TRY(ctx, hipMalloc(&pl->win_arena, bytes));
+    char* base = (char*)pl->win_arena;
+    HIP_TRY(ctx, hipMemcpy(base + o_pw, pw.data(), sizeof(int32_t) * std::max(nf, 1), hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(base + o_qw, point_window, sizeof(int32_t) * NL, hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(base + o_ptr, ptr.data(), sizeof(int32_t) * (n_windows + 1), hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(base + o_lst, lst.data(), sizeof(int32_t) * NL, hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemset(base + o_lam, 0, sizeof(double) * n_windows));
+    d.n_windows = n_windows; d.pose_win = (int32_t*)(base + o_pw); d.point_win = (int32_t*)(base + o_qw);
+    d.win_pt_ptr = (int32_t*)(base + o_ptr); d.win_pt = (int32_t*)(base + o_lst); d.lam_w = (double*)(base + o_lam); d.win_out = (double*)(base + o_out);
+    pl->d_lam = (double*)(base + o_lam);
+    return MSLAM_OK;
+}
+
 int mslam_ba_plan_build_dev(mslam_ba_plan* pl)
 {
     if (!pl) return MSLAM_ERR_INVALID;
     mslam_ctx* ctx = pl->ctx;
     MSLAM_TRY(ctx_set_device(ctx));
     const BaDev& d = pl->dev;
-    hipStream_t st = ctx->stream;
-    const int groups_per_block = BA_THREADS / GROUP;
-    LAUNCH(ctx, K_BA_POINTS, ba_points_k, dim3((d.n_points + groups_per_block - 1) / groups_per_block), dim3(BA_THREADS), 0, d);
-    if (d.n_free > 0 && d.nnzb > 0)
-        LAUNCH(ctx, K_BA_POSES, ba_poses_k, dim3(d.n_chunks_max, d.n_free), dim3(POSE_CHUNK), 0, d);
+    LAUNCH(ctx, K_BA_POSES, ba_edges_k, dim3(d.n_chunks_max, d.n_rows), dim3(EDGE_CHUNK), 0, d);
+    LAUNCH(ctx, K_BA_POINTS, ba_points_k, dim3((d.n_points + 255) / 256), dim3(256), 0, d);
     if (d.n_points <= 2 * CHI_SLICE && d.n_free * 27 <= 4096) {
         LAUNCH(ctx, K_BA_FINAL, ba_final_k, dim3(1), dim3(256), 0, d, 0);
     } else {
         const int n_pose_wg = (d.n_free * 27 + 255) / 256, n_slices = (d.n_points + CHI_SLICE - 1) / CHI_SLICE;
         LAUNCH(ctx, K_BA_FINAL, ba_final_k, dim3(n_pose_wg + n_slices), dim3(256), 0, d, n_pose_wg);
-        LAUNCH(ctx, K_BA_FINAL, ba_final2_k, dim3(1), dim3(256), 0, d, n_slices);
+        LAUNCH(ctx, K_BA_FINAL, ba_final2_k, dim3(1), dim3(256), 0, (const double*)d.chi_part, n_slices, d.robust_chi2);
     }
+    if (d.n_windows > 1) LAUNCH(ctx, K_BA_FINAL, ba_window_sums_k, dim3(d.n_windows), dim3(256), 0, d, 0);
     HIP_TRY(ctx, hipGetLastError());
     return MSLAM_OK;
 }
@@ -664,22 +902,41 @@ int mslam_ba_plan_download(mslam_ba_plan* pl, mslam_ba_system* s)
     return MSLAM_OK;
 }
 
+static int schur_launch(mslam_ba_plan* pl)
+{
+    mslam_ctx* ctx = pl->ctx;
+    const BaDev& d = pl->dev;
+    const size_t n6 = 6 * (size_t)d.n_free;
+    HIP_TRY(ctx, hipMemsetAsync(d.S, 0, sizeof(double) * n6 * n6, ctx->stream));   // pose pairs that share no point
+    LAUNCH(ctx, K_BA_SCHUR, ba_schur_points_k, dim3((d.n_points + 255) / 256), dim3(256), 0, d);
+    LAUNCH(ctx, K_BA_SCHUR_TILES, ba_schur_tiles_k, dim3(d.n_tiles), dim3(256), 0, d);
+    const long long items = (long long)d.n_gpairs * 36 * FIN_SPLIT;
+    LAUNCH(ctx, K_BA_SCHUR_FINAL, ba_schur_final_k, dim3((unsigned)std::min<long long>(4096, (items + 255) / 256 + 1)), dim3(256), 0, d);
+    HIP_TRY(ctx, hipGetLastError());
+    return MSLAM_OK;
+}
+
 int mslam_ba_plan_schur_dev(mslam_ba_plan* pl, double lambda)
 {
     if (!pl) return MSLAM_ERR_INVALID;
     if (!pl->has_schur) return MSLAM_ERR_CAPACITY;
     mslam_ctx* ctx = pl->ctx;
     MSLAM_TRY(ctx_set_device(ctx));
-    BaDev d = pl->dev;
-    d.lambda = lambda;
-    pl->dev.lambda = lambda;
-    const int npairs = d.n_free * (d.n_free + 1) / 2;
-    LAUNCH(ctx, K_BA_SCHUR, ba_schur_points_k, dim3((d.n_points + 255) / 256), dim3(256), 0, d);
-    LAUNCH(ctx, K_BA_SCHUR, ba_schur_blocks_k, dim3((d.nnzb + 255) / 256), dim3(256), 0, d);
-    LAUNCH(ctx, K_BA_SCHUR, ba_schur_pairs_k, dim3(d.n_chunks_max, npairs), dim3(POSE_CHUNK), 0, d);
-    LAUNCH(ctx, K_BA_SCHUR, ba_schur_final_k, dim3(std::min(64, (npairs * 36 + 255) / 256)), dim3(256), 0, d);
-    HIP_TRY(ctx, hipGetLastError());
-    return MSLAM_OK;
+    std::vector<double> lam((size_t)pl->dev.n_windows, lambda);   // one lambda for every window
+    HIP_TRY(ctx, hipMemcpyAsync(pl->d_lam, lam.data(), sizeof(double) * lam.size(), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return schur_launch(pl);
+}
+
+int mslam_ba_plan_schur_windows_dev(mslam_ba_plan* pl, const double* lambda_per_window)
+{
+    if (!pl || !lambda_per_window) return MSLAM_ERR_INVALID;
+    if (!pl->has_schur) return MSLAM_ERR_CAPACITY;
+    mslam_ctx* ctx = pl->ctx;
+    MSLAM_TRY(ctx_set_device(ctx));
+    HIP_TRY(ctx, hipMemcpyAsync(pl->d_lam, lambda_per_window, sizeof(double) * pl->dev.n_windows, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // lambda_per_window may be a temporary of the caller
+    return schur_launch(pl);
 }
 
 int mslam_ba_plan_download_schur(mslam_ba_plan* pl, double* S, double* bs)
@@ -703,9 +960,11 @@ int mslam_ba_plan_backsub_dev(mslam_ba_plan* pl, const double* x_pose_host, int 
     const BaDev& d = pl->dev;
     HIP_TRY(ctx, hipMemcpyAsync(d.x, x_pose_host, sizeof(double) * 6 * d.n_free, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); // x_pose_host may be a temporary of the caller
-    const int nb = (d.n_points + 255) / 256;
-    LAUNCH(ctx, K_BA_SCHUR, ba_backsub_k, dim3(nb), dim3(256), 0, d, apply_to_points, pl->d_points);
-    LAUNCH(ctx, K_BA_SCHUR, ba_scale_final_k, dim3(1), dim3(64), 0, d, nb);
+    LAUNCH(ctx, K_BA_BACKSUB, ba_backsub_k, dim3((d.n_points + 255) / 256), dim3(256), 0, d, apply_to_points, pl->d_points);
+    const int n_slices = (d.n_points + CHI_SLICE - 1) / CHI_SLICE;
+    LAUNCH(ctx, K_BA_BACKSUB, ba_slice_sum_k, dim3(n_slices), dim3(256), 0, (const double*)d.pt_scale, d.n_points, d.scale_part);
+    LAUNCH(ctx, K_BA_BACKSUB, ba_final2_k, dim3(1), dim3(256), 0, (const double*)d.scale_part, n_slices, d.scale_l);
+    if (d.n_windows > 1) LAUNCH(ctx, K_BA_BACKSUB, ba_window_sums_k, dim3(d.n_windows), dim3(256), 0, d, 1);
     HIP_TRY(ctx, hipGetLastError());
     return MSLAM_OK;
 }
@@ -719,6 +978,19 @@ int mslam_ba_plan_download_x(mslam_ba_plan* pl, double* x, double* scale_landmar
     if (x) HIP_TRY(ctx, hipMemcpyAsync(x, d.x, sizeof(double) * (6 * d.n_free + 3 * (size_t)d.n_points), hipMemcpyDeviceToHost, ctx->stream));
     if (scale_landmarks) HIP_TRY(ctx, hipMemcpyAsync(scale_landmarks, d.scale_l, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return MSLAM_OK;
+}
+
+int mslam_ba_plan_download_window_sums(mslam_ba_plan* pl, double* robust_chi2, double* scale_landmarks)
+{
+    if (!pl || pl->dev.n_windows < 2 || !pl->dev.win_out) return MSLAM_ERR_INVALID;
+    mslam_ctx* ctx = pl->ctx;
+    MSLAM_TRY(ctx_set_device(ctx));
+    const int W = pl->dev.n_windows;
+    std::vector<double> h((size_t)2 * W);
+    HIP_TRY(ctx, hipMemcpyAsync(h.data(), pl->dev.win_out, sizeof(double) * 2 * W, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (int w = 0; w < W; w++) { if (robust_chi2) robust_chi2[w] = h[2 * w]; if (scale_landmarks) scale_landmarks[w] = h[2 * w + 1]; }
     return MSLAM_OK;
 }
 

@@ -49,9 +49,10 @@ __constant__ int c_gk[7] = { 18, 34, 49, 55, 49, 34, 18 };
 // 4 pixels = 32 LDS dwords; outputs are the inner 126 x 62.  The pixel tile (score region + 3 px ring) is staged so
 // that score column 0 sits on a dword boundary: LDS byte (c + 1) of a row holds tile column c.
 constexpr int FS_W = 128, FS_H = 64;              // score region
-constexpr int FT_W = FS_W - 2, FT_H = FS_H - 2;   // outputs per tile (126 x 62)
+constexpr int FT_W = FS_W - 4, FT_H = FS_H - 2;   // outputs per tile (124 x 62): the tile step in x is a multiple of 4 so that
+                                                  // every tile's pixel window starts on an image dword (aligned LDS-DMA staging)
 constexpr int FP_H = FS_H + 6;                    // pixel tile rows (70)
-constexpr int FP_PITCH = 136;                     // LDS row pitch in bytes (34 dwords: 134 columns + 2 pad)
+constexpr int FP_PITCH = 144;                     // LDS row pitch in bytes: 9 chunks of 16 B (134 columns used)
 constexpr int FAST_THREADS = 512;                 // 128 x 64 tiles with 8 wavefronts: 0.273 -> 0.260 ms vs 128 x 32 / 4 (128 x 128 / 16: 0.275)
 constexpr int CNT_STRIDE = 32;                    // candidate counters one per 128-byte line: tiles of different
                                                   // (frame, level) pairs must not serialise on one L2 atomic unit
@@ -60,6 +61,7 @@ struct LevelDesc {
     uint8_t* img; int w, h, pitch; long long frame_stride; // bytes
     int roi_x0, roi_y0, roi_w, roi_h;  // [edge, w-edge) x [edge, h-edge)
     int tiles_x, tiles_y, tile_base;   // tile_base: first tile index of this level in the all-level grid
+    int tile_x0;                       // image x of the first tile's first output column: <= roi_x0, == 1 (mod 4)
     int cand_cap; uint32_t* cand; uint32_t* candA; float* respA;
     int nfeat; float sf, inv_sf;
     int2* xtab; int4* ytab;            // resize tables for producing THIS level from l-1
@@ -82,6 +84,15 @@ __device__ __forceinline__ unsigned xcd_contiguous(unsigned orig, unsigned nwg)
 {
     const unsigned q = nwg >> 3, r = nwg & 7u, xcd = orig & 7u;
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+}
+
+// LDS-DMA: 16 bytes per lane from a per-lane global address straight into LDS at (wave-uniform) lds_wave_base + lane * 16.
+// No VGPR round trip; completion is tracked by vmcnt (a following __syncthreads() waits for it).
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base)
+{
+    typedef __attribute__((address_space(1))) const void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    __builtin_amdgcn_global_load_lds((gptr_t)gsrc, (lptr_t)lds_wave_base, 16, 0, 0);
 }
 
 // ---------------------------------------------------------------- K1: gray + pyramid
@@ -275,35 +286,31 @@ void fast_nms_k(OrbDev od)
     const LevelDesc& lv = od.lv[l];
     t -= lv.tile_base;
     const int tx = t % lv.tiles_x, ty = t / lv.tiles_x;
-    const int ox = lv.roi_x0 + tx * FT_W, oy = lv.roi_y0 + ty * FT_H; // first output pixel
+    const int ox = lv.tile_x0 + tx * FT_W, oy = lv.roi_y0 + ty * FT_H; // first output pixel (ox % 4 == 1; ox <= roi_x0 for tx == 0)
     const uint8_t* img = lv.img + b * lv.frame_stride;
     const int tid = threadIdx.x;
 
     if (tid == 0) { s_n1 = 0; s_ne = 0; }
     for (int i = tid; i < FS_H * FS_W / 4; i += FAST_THREADS) reinterpret_cast<uint32_t*>(s_score)[i] = 0;
-    // ---- stage the pixel tile: LDS dword j of row r = image bytes x = (ox - 5 + 4j) .. +3 of row (oy - 4 + r),
-    // assembled from two aligned global dwords with v_alignbyte (the tile origin is not dword aligned).  A half
-    // wavefront takes dwords 0..31 of one row (8 rows per pass); the two remaining dwords of every row go last.
+    // ---- stage the pixel tile by LDS-DMA: LDS byte i of row r = image byte x = (ox - 5 + i) of row (oy - 4 + r).  The tile
+    // grid is laid out so that ox - 5 is a multiple of 4 (level rows are dword aligned), hence score column 0 sits on an LDS
+    // dword boundary with no realignment.  One global_load_lds_dwordx4 moves 64 chunks of 16 B (lane-linear in LDS); 630
+    // chunks per tile = 10 wave-instructions for the whole workgroup, no VGPR round trip.  Chunks that would start beyond
+    // (row end - 16) are clamped: they only hold columns past the ROI + 4, which nothing reads.
     {
-        const int gx0 = ox - 5;                 // >= 17 (edge >= 22)
-        const int sh = gx0 & 3, a0 = gx0 >> 2;
-        const int max_dw = lv.pitch / 4 - 1, pitch_dw = lv.pitch / 4;
-        const uint32_t* img32 = reinterpret_cast<const uint32_t*>(img);
-        static_assert(FP_PITCH / 4 == 34, "staging assumes 32 + 2 dwords per row");
-        const int j = tid & 31;
-        const int c0 = min(a0 + j, max_dw), c1 = min(a0 + j + 1, max_dw);
+        const int gx0 = ox - 5;                 // >= 16, multiple of 4
+        constexpr int NCHUNK = FP_H * (FP_PITCH / 16);
+        static_assert(FP_PITCH % 16 == 0, "16-byte LDS-DMA chunks");
+        const int wv = tid >> 6, ln = tid & 63;
 #pragma unroll
-        for (int r0 = 0; r0 < FP_H; r0 += FAST_THREADS / 32) {
-            const int r = r0 + (tid >> 5);
-            if (r < FP_H) {
-                const int rowo = min(oy - 4 + r, lv.h - 1) * pitch_dw;
-                s_pix[r * (FP_PITCH / 4) + j] = __builtin_amdgcn_alignbyte(img32[rowo + c1], img32[rowo + c0], sh);
+        for (int c0 = 0; c0 < NCHUNK; c0 += FAST_THREADS) {
+            const int cb = c0 + wv * 64;        // wave-uniform first chunk of this instruction
+            const int c = cb + ln;
+            if (c < NCHUNK) {
+                const int r = c / (FP_PITCH / 16), k = c - r * (FP_PITCH / 16);
+                const uint8_t* g = img + (size_t)min(oy - 4 + r, lv.h - 1) * lv.pitch + min(gx0 + 16 * k, lv.pitch - 16);
+                glds16(g, reinterpret_cast<uint8_t*>(s_pix) + cb * 16);
             }
-        }
-        if (tid < 2 * FP_H) {
-            const int r = tid >> 1, jj = 32 + (tid & 1);
-            const int rowo = min(oy - 4 + r, lv.h - 1) * pitch_dw;
-            s_pix[r * (FP_PITCH / 4) + jj] = __builtin_amdgcn_alignbyte(img32[rowo + min(a0 + jj + 1, max_dw)], img32[rowo + min(a0 + jj, max_dw)], sh);
         }
     }
     __syncthreads();
@@ -384,11 +391,12 @@ void fast_nms_k(OrbDev od)
     if (od.ablate == 3) return;
     // ---- phase 3: 3x3 non-max suppression on the score tile, outputs inside the ROI only
     const int out_w = min(FT_W, lv.roi_x0 + lv.roi_w - ox), out_h = min(FT_H, lv.roi_y0 + lv.roi_h - oy);
+    const int out_x0 = 1 + max(0, lv.roi_x0 - ox);   // the first tile column starts up to 3 px left of the ROI
     for (int j = tid; j < n1; j += FAST_THREADS) {
         const int i = s_list[j];
         const int sy = i / FS_W, sx = i % FS_W;
         const int sc = s_score[i];
-        if (sc == 0 || sx < 1 || sy < 1 || sx > out_w || sy > out_h) continue;
+        if (sc == 0 || sx < out_x0 || sy < 1 || sx > out_w || sy > out_h) continue;
         const uint8_t* c = s_score + i;
         const bool mx = sc > c[-1] && sc > c[1] && sc > c[-FS_W - 1] && sc > c[-FS_W] && sc > c[-FS_W + 1] &&
                         sc > c[FS_W - 1] && sc > c[FS_W] && sc > c[FS_W + 1];
@@ -862,7 +870,8 @@ static int orb_plan_get(mslam_ctx* ctx, int w, int h, int B, int channels, const
         lv.roi_x0 = edge; lv.roi_y0 = edge;
         lv.roi_w = lv.w - 2 * edge; lv.roi_h = lv.h - 2 * edge;
         if (lv.roi_w <= 0 || lv.roi_h <= 0) { lv.roi_w = 0; lv.roi_h = 0; }
-        lv.tiles_x = (lv.roi_w + FT_W - 1) / FT_W; lv.tiles_y = (lv.roi_h + FT_H - 1) / FT_H;
+        lv.tile_x0 = lv.roi_x0 - ((lv.roi_x0 - 1) & 3);
+        lv.tiles_x = lv.roi_w > 0 ? (lv.roi_x0 + lv.roi_w - lv.tile_x0 + FT_W - 1) / FT_W : 0; lv.tiles_y = (lv.roi_h + FT_H - 1) / FT_H;
         lv.tile_base = tile_base;
         tile_base += lv.tiles_x * lv.tiles_y;
         lv.cand_cap = ((lv.roi_w + 1) / 2) * ((lv.roi_h + 1) / 2) + 1;

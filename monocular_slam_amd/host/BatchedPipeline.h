@@ -1,0 +1,56 @@
+// BatchedPipeline -- ProcessingPipeline(FeatureExtractor -> CameraPoseEstimator) for B independent sequences at once.
+// The reference runs one sequence, one frame at a time, single-threaded (src/main.cpp:40-51, src/Pipeline.h:49-65); frame i
+// of a sequence depends on frame i-1 of the same sequence only (src/CameraPoseEstimator.cpp:388,405), so B sequences can
+// share every launch.  process(i) does for all of them what ProcessingPipeline::process(dm, i) does for one:
+//   FeatureExtractor::process  (src/FeatureExtractor.cpp:13-31)   one mslam_orb_extract_batch_dev over B frames; features stay
+//                                                                  on the device in a ring of the last 1 + numBackTraverse frames
+//   CameraPoseEstimator::process (src/CameraPoseEstimator.cpp:517-530)
+//     matchFeatures :200-213       mslam_match_knn2_batch_dev on the device-resident descriptors (no upload, ratio test on device)
+//     computeFundamentalMatrix :545-586   mslam_fmat_ransac8_batch_dev over the B match sets
+//     solvePnPRansac :472          mslam_pnp_ransac_batch_dev over the B 3D-2D sets
+//   association, essential-matrix decomposition, cheirality vote and map bookkeeping run per stream on the host, as in the
+//   reference (:218-243, :316-356, :432-452).
+// Every stream gets exactly what the single-stream ProcessingPipeline of this repository gives it (same kernels, same
+// parameters, same sample tables): tests/test_pipeline_gpu.py compares the two.  Frame.features.descriptors is filled lazily
+// (descriptors()/syncFeatures()) -- nothing in the batched stages needs it on the host.
+#pragma once
+#include <memory>
+#include <vector>
+#include "MultiStreamRunner.h"
+#include "Stages.h"
+
+class BatchedPipeline {
+public:
+    // the stage objects carry the parameters (same defaults as the single-stream stages)
+    BatchedPipeline(std::vector<DataManager*> streams, const FeatureExtractor& fe = FeatureExtractor(),
+                    const CameraPoseEstimator& cpe = CameraPoseEstimator(), int device = 0);
+    ~BatchedPipeline();
+    int streams() const { return (int)dms_.size(); }
+    // one tick: frames[frameIdx] of every stream (all must have the same size / channel count)
+    void process(int frameIdx);
+    // host copy of frame `frameIdx`'s descriptors for one stream (downloads on first use while the frame is still in the ring)
+    const cv::Mat& descriptors(int stream, int frameIdx);
+    std::vector<int> lastStatus;       // per stream: MSLAM_OK or the status that made the pose stage keep the previous pose
+    MultiStreamRunner* runner() { return runner_.get(); }
+    bool eagerDescriptors = false;     // true: fill Frame.features.descriptors for every frame right after extraction
+
+private:
+    void extractAll(int frameIdx);
+    void poseInitial(int frameIdx);
+    void posePnp(int frameIdx);
+    struct MatchSet { std::vector<int32_t> count, query, train; std::vector<float> dist; };
+    void matchAll(int slotQ, int slotT, float ratio, MatchSet& out);
+    // F RANSAC over the B match sets: x1 = positions of the query frame, x2 = of the train frame
+    void fmatAll(const std::vector<const Frame*>& fq, const std::vector<const Frame*>& ft, const MatchSet& ms, const std::vector<uint64_t>& seeds,
+                 std::vector<double>& F, std::vector<std::vector<uint8_t>>& status, std::vector<int>& rc);
+    int slotOf(int frameIdx) const { return frameIdx % ring_; }
+    void* scratch(int slot, size_t bytes);
+
+    std::vector<DataManager*> dms_;
+    FeatureExtractor fe_;
+    CameraPoseEstimator cpe_;
+    int device_, ring_, w_ = 0, h_ = 0, ch_ = 0;
+    std::unique_ptr<MultiStreamRunner> runner_;
+    void* pinned_ = nullptr; size_t pinned_bytes_ = 0;
+    void* dscratch_[4] = { nullptr, nullptr, nullptr, nullptr }; size_t dscratch_bytes_[4] = { 0, 0, 0, 0 };
+};

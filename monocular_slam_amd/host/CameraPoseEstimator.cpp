@@ -43,12 +43,35 @@ void CameraPoseEstimator::matchFeatures(const cv::Mat& d1, const cv::Mat& d2, st
     matches.clear();
     const int nq = d1.rows, nt = d2.rows;
     if (nq == 0 || nt < 2) return; // the reference indexes raw_matches[i][1] unguarded (:209); here: no matches
-    std::vector<int32_t> idx((size_t)nq * 2), dist((size_t)nq * 2), qi((size_t)nq), ti((size_t)nq);
+    std::vector<int32_t> qi((size_t)nq), ti((size_t)nq);
     std::vector<float> dd((size_t)nq);
     MslamRuntime& rt = MslamRuntime::instance();
-    MslamRuntime::check(mslam_match_knn2(rt.ctx(), d1.data, nq, d2.data, nt, idx.data(), dist.data()), "mslam_match_knn2");
     int n = 0;
-    MslamRuntime::check(mslam_ratio_filter(idx.data(), dist.data(), nq, ratio, qi.data(), ti.data(), dd.data(), &n), "mslam_ratio_filter");
+    DeviceFeatures* a = rt.deviceFeatures(d1.device);
+    DeviceFeatures* b = rt.deviceFeatures(d2.device);
+    if (a && b && a->cap == b->cap && a->n == nq && b->n == nt) {
+        // both descriptor sets are still on the device (left there by FeatureExtractor::extract): kNN-2, ratio test and the
+        // ordered compaction run there, only the surviving (query, train, distance) triples come back
+        const size_t cap = (size_t)a->cap;
+        uint8_t* out = (uint8_t*)rt.scratch(2, cap * (2 * 4 * 2 + 3 * 4) + 256);
+        int32_t* idx = (int32_t*)out; int32_t* dist = idx + 2 * cap;
+        int32_t* mq = dist + 2 * cap; int32_t* mt = mq + cap; float* md = (float*)(mt + cap); int32_t* mc = (int32_t*)(md + cap);
+        MslamRuntime::check(mslam_match_knn2_batch_dev(rt.ctx(), a->desc, a->n_dev, b->desc, b->n_dev, (int)cap, 1, idx, dist, ratio, mq, mt, md, mc),
+                            "mslam_match_knn2_batch_dev");
+        int32_t hc = 0;
+        MslamRuntime::check(mslam_memcpy_d2h(rt.ctx(), &hc, mc, sizeof(hc)), "mslam_memcpy_d2h");
+        n = hc;
+        if (n > 0) {
+            MslamRuntime::check(mslam_memcpy_d2h_async(rt.ctx(), qi.data(), mq, sizeof(int32_t) * (size_t)n), "mslam_memcpy_d2h_async");
+            MslamRuntime::check(mslam_memcpy_d2h_async(rt.ctx(), ti.data(), mt, sizeof(int32_t) * (size_t)n), "mslam_memcpy_d2h_async");
+            MslamRuntime::check(mslam_memcpy_d2h(rt.ctx(), dd.data(), md, sizeof(float) * (size_t)n), "mslam_memcpy_d2h");
+        }
+    } else {
+        // host-pointer form (descriptors that did not come from this process's extract, e.g. loaded fixtures)
+        std::vector<int32_t> idx((size_t)nq * 2), dist((size_t)nq * 2);
+        MslamRuntime::check(mslam_match_knn2(rt.ctx(), d1.data, nq, d2.data, nt, idx.data(), dist.data()), "mslam_match_knn2");
+        MslamRuntime::check(mslam_ratio_filter(idx.data(), dist.data(), nq, ratio, qi.data(), ti.data(), dd.data(), &n), "mslam_ratio_filter");
+    }
     matches.resize((size_t)n);
     for (int i = 0; i < n; i++) { matches[(size_t)i].queryIdx = qi[(size_t)i]; matches[(size_t)i].trainIdx = ti[(size_t)i]; matches[(size_t)i].distance = dd[(size_t)i]; }
 }

@@ -3,12 +3,19 @@
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
+#include <new>
 #include <vector>
 
 namespace imageio {
 namespace {
 
 bool fail(std::string* err, const std::string& m) { if (err) *err = m; return false; }
+
+// Header dimensions come from the file: refuse anything a camera frame cannot be before allocating for it
+// (the reference's FrameLoader only ever sees 640x480 .. 1920x1080 frames, src/FrameLoader.cpp:171-214).
+constexpr int kMaxDim = 16384;
+constexpr size_t kMaxSamples = (size_t)1 << 28;   // w * h * channels
+bool saneSize(int w, int h, int ch) { return w >= 1 && h >= 1 && w <= kMaxDim && h <= kMaxDim && ch >= 1 && (size_t)w * h * ch <= kMaxSamples; }
 
 bool readFile(const std::string& path, std::vector<uint8_t>& buf)
 {
@@ -53,6 +60,7 @@ bool decodePng(const std::vector<uint8_t>& f, int& w, int& h, int& ch, int& dept
         pos += 12 + (size_t)len;
     }
     if (w <= 0 || h <= 0 || ctype < 0) return fail(err, "PNG without IHDR");
+    if (!saneSize(w, h, 4)) return fail(err, "PNG dimensions out of range");
     if (interlace) return fail(err, "interlaced PNG is not supported");
     int fch;
     switch (ctype) { case 0: fch = 1; break; case 2: fch = 3; break; case 3: fch = 1; break; case 4: fch = 2; break; case 6: fch = 4; break;
@@ -108,13 +116,15 @@ bool decodePnm(const std::vector<uint8_t>& f, int& w, int& h, int& ch, int& dept
     while (nv < 3 && pos < f.size()) {
         if (f[pos] == '#') { while (pos < f.size() && f[pos] != '\n') pos++; continue; }
         if (isspace(f[pos])) { pos++; continue; }
-        int v = 0;
-        while (pos < f.size() && isdigit(f[pos])) v = v * 10 + (f[pos++] - '0');
-        vals[nv++] = v;
+        if (!isdigit(f[pos])) return fail(err, "bad PNM header");
+        long v = 0;
+        while (pos < f.size() && isdigit(f[pos])) { v = v * 10 + (f[pos++] - '0'); if (v > 65535) return fail(err, "PNM header value out of range"); }
+        vals[nv++] = (int)v;
     }
     pos++; // the single whitespace after maxval
     if (nv < 3) return fail(err, "bad PNM header");
     w = vals[0]; h = vals[1]; depth = vals[2] > 255 ? 16 : 8;
+    if (!saneSize(w, h, ch) || vals[2] < 1) return fail(err, "PNM dimensions / maxval out of range");
     const size_t n = (size_t)w * h * ch, need = n * (depth / 8);
     if (pos + need > f.size()) return fail(err, "truncated PNM data");
     samples.resize(n);
@@ -139,10 +149,14 @@ bool imread(const std::string& path, cv::Mat& out, int flags, std::string* err)
     int w = 0, h = 0, ch = 0, depth = 8;
     std::vector<uint16_t> s;
     bool ok;
-    if (hasSuffix(path, ".png")) ok = decodePng(f, w, h, ch, depth, s, err);
-    else if (hasSuffix(path, ".pgm") || hasSuffix(path, ".ppm") || hasSuffix(path, ".pnm")) ok = decodePnm(f, w, h, ch, depth, s, err);
-    else return fail(err, "unsupported image type (PNG and binary PGM/PPM only): " + path);
+    try {
+        if (hasSuffix(path, ".png")) ok = decodePng(f, w, h, ch, depth, s, err);
+        else if (hasSuffix(path, ".pgm") || hasSuffix(path, ".ppm") || hasSuffix(path, ".pnm")) ok = decodePnm(f, w, h, ch, depth, s, err);
+        else return fail(err, "unsupported image type (PNG and binary PGM/PPM only): " + path);
+    } catch (const std::bad_alloc&) { return fail(err, "out of memory decoding " + path); }
     if (!ok) return false;
+    // 16-bit files are narrowed to 8 bits here (>> 8); the reference's imread(CV_LOAD_IMAGE_UNCHANGED) would keep CV_16U
+    // (src/FrameLoader.cpp:62) -- its ORB stage cannot take such frames either, so nothing on the path depends on it
     if (flags == LOAD_ANYDEPTH_F32) { // depth maps: first channel, native depth, as float
         out.create(h, w, cv::CV_32F);
         for (int y = 0; y < h; y++) for (int x = 0; x < w; x++) out.at<float>(y, x) = (float)s[((size_t)y * w + x) * ch];

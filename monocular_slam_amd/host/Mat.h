@@ -32,7 +32,7 @@ public:
     Mat() = default;
     Mat(int r, int c, int type) { create(r, c, type); }
     void create(int r, int c, int type) {
-        rows = r; cols = c; type_ = type;
+        rows = r; cols = c; type_ = type; device.reset();
         step = (size_t)c * elemSize();
         buf_ = std::shared_ptr<uint8_t>(new uint8_t[step * (size_t)r + 8](), std::default_delete<uint8_t[]>());
         data = buf_.get();
@@ -43,7 +43,7 @@ public:
     int channels() const { return cv_channels(type_); }
     size_t elemSize() const { return (size_t)cv_elem_size1(cv_depth(type_)) * cv_channels(type_); }
     bool empty() const { return data == nullptr || rows == 0 || cols == 0; }
-    Mat clone() const { Mat m; if (!empty()) { m.create(rows, cols, type_); std::memcpy(m.data, data, step * (size_t)rows); } return m; }
+    Mat clone() const { Mat m; if (!empty()) { m.create(rows, cols, type_); std::memcpy(m.data, data, step * (size_t)rows); } return m; } // no device twin
     template <typename T> T& at(int r, int c) { return *reinterpret_cast<T*>(data + step * (size_t)r + sizeof(T) * (size_t)c); }
     template <typename T> const T& at(int r, int c) const { return *reinterpret_cast<const T*>(data + step * (size_t)r + sizeof(T) * (size_t)c); }
     template <typename T> T& at(int i) { return reinterpret_cast<T*>(data)[i]; }
@@ -52,6 +52,10 @@ public:
     template <typename T> const T* ptr(int r = 0) const { return reinterpret_cast<const T*>(data + step * (size_t)r); }
     uint8_t* data = nullptr;
     size_t step = 0;
+    // Optional device-resident twin of the contents (cv::UMat's role): an opaque owning handle that shallow copies share
+    // and clone() drops.  FeatureExtractor attaches the frame's descriptors on the GPU here so that matchFeatures can
+    // match without uploading them again (Runtime.h: DeviceFeatures).  Whoever writes through `data` must reset it.
+    std::shared_ptr<void> device;
 private:
     int type_ = 0;
     std::shared_ptr<uint8_t> buf_;

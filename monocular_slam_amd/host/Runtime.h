@@ -1,8 +1,23 @@
-// Runtime.h -- process-wide handle on the C ABI context (one per GPU) shared by the stages.
+// Runtime.h -- process-wide handle on the C ABI context (one per GPU) shared by the stages, plus the device-side
+// resources the single-stream stages keep between calls so that features do not bounce through the host:
+// a frame's descriptors stay on the GPU (DeviceFeatures, attached to Features::descriptors as cv::Mat::device) from
+// FeatureExtractor::extract until the last cv::Mat copy that refers to them dies; CameraPoseEstimator::matchFeatures
+// matches two such twins with mslam_match_knn2_batch_dev without any upload (the reference keeps everything in host
+// cv::Mats, src/Frame.h:22-34 -- there is no device there to keep anything on).
 #pragma once
+#include <memory>
 #include <stdexcept>
 #include <string>
+#include <vector>
 #include "../../include/mslam.h"
+
+// descriptors of one frame on the device: cap x 32 bytes + the row count as a device int32 (what the _dev entry points take)
+struct DeviceFeatures {
+    uint64_t gen = 0;          // runtime generation this buffer belongs to (a re-created context invalidates older ones)
+    uint8_t* desc = nullptr;   // cap x 32, 256-byte aligned
+    int32_t* n_dev = nullptr;  // 1 int32: number of rows
+    int n = 0, cap = 0;
+};
 
 class MslamRuntime {
 public:
@@ -13,9 +28,24 @@ public:
     static void check(int status, const char* what) {
         if (status != MSLAM_OK) throw std::runtime_error(std::string(what) + ": " + mslam_strerror(status));
     }
+    // a descriptor buffer from the pool (returned to it when the last owner lets go)
+    std::shared_ptr<DeviceFeatures> newDeviceFeatures(int cap);
+    // the twin behind a cv::Mat::device handle if it is still valid on the current context, else nullptr
+    DeviceFeatures* deviceFeatures(const std::shared_ptr<void>& handle) const;
+    // grow-only device scratch of the single-stream stages (slot 0: image upload, 1: keypoints + status, 2: match outputs)
+    void* scratch(int slot, size_t bytes);
     ~MslamRuntime();
 private:
     MslamRuntime() = default;
+    void release();
     mslam_ctx* ctx_ = nullptr;
     int w_ = 0, h_ = 0, kp_ = 0;
+    uint64_t gen_ = 1;
+    struct Pool { int cap; std::vector<void*> free; };
+    std::vector<Pool> pools_;
+    std::vector<void*> owned_;            // every pool buffer ever allocated on this context
+    void* scratch_[4] = { nullptr, nullptr, nullptr, nullptr };
+    size_t scratch_bytes_[4] = { 0, 0, 0, 0 };
+    static bool alive_;
+    friend struct DeviceFeaturesDeleter;
 };

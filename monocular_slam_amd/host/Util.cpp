@@ -351,6 +351,10 @@ void Util::runBA(DataManager& data, std::vector<Frame>& frames, std::vector<MapP
     // ---- write back (src/Util.cpp:184-219)
     if (write_back) {
         for (size_t k = 0; k < poseOfFrame.size(); k++) {
+            // fixed poses did not move: leave their Rt alone instead of sending it through the quaternion round trip (which
+            // may flip last bits; the reference writes every vertex back, but its only fixed vertex is frame 0 = identity,
+            // for which the round trip is exact)
+            if (fixed[k]) continue;
             double Rt[12];
             geom::SE3QuatToRt(&poses[7 * k], Rt);                      // Converter::SE3QuatToCvMat
             cv::Mat m(3, 4, cv::CV_64F);

@@ -115,6 +115,18 @@ def main():
     t = gpu_time(ctx, planB.build_dev, reps=20, tag='ba_x%d' % B)
     EB = prB["n_edges"]
     out["C3 BA build, %d windows per launch" % B] = dict(unit="builds/s", gpu=B / t, cpu=1 / tc, alg_bytes=216 * EB / B, gpu_edges_per_s=EB / t, edges=EB)
+    # ---- one LM iteration's device work for those B windows: build + Schur (own lambda per window) + back-substitution
+    pose_w = np.repeat(np.arange(B, dtype=np.int32), 10); point_w = np.repeat(np.arange(B, dtype=np.int32), 5000)
+    planB.set_windows(pose_w, point_w, B)
+    lamB = np.full(B, 10.0)
+    n6 = 6 * planB.view.n_free_poses
+    xp = np.zeros(n6)
+
+    def lm_iter():
+        planB.build_dev(); planB.schur_windows_dev(lamB); planB.backsub_dev(xp, True)
+    t = gpu_time(ctx, lm_iter, reps=10, tag='lm_x%d' % B)
+    out["C3 LM iteration (build + Schur + back-subst), %d windows per launch" % B] = dict(unit="window-iterations/s", gpu=B / t, cpu=1 / cpu_time(lambda: ob.ba_schur(pr, 10.0)),
+                                                                                         alg_bytes=216 * EB / B, gpu_edges_per_s=EB / t, edges=EB)
     planB.close()
     for k, v in out.items():
         v["gpu_alg_GBps"] = v["gpu"] * v["alg_bytes"] / 1e9

@@ -35,7 +35,7 @@ def _built_artifacts(request):
     import subprocess
     lib = os.path.join(ROOT, "monocular_slam_amd", "libmslam_hip.so")
     host = os.path.join(ROOT, "monocular_slam_amd", "host")
-    demos = [os.path.join(host, n) for n in ("libmslam_host.so", "mslam_pipeline_demo", "mslam_ba_csv_demo", "mslam_sequence_demo", "mslam_imageio_check", "mslam_geometry_check", "mslam_util_check")]
+    demos = [os.path.join(host, n) for n in ("libmslam_host.so", "mslam_bench", "mslam_batched_demo", "mslam_pipeline_demo", "mslam_ba_csv_demo", "mslam_sequence_demo", "mslam_imageio_check", "mslam_geometry_check", "mslam_util_check")]
     try:
         if not os.path.exists(lib):
             subprocess.run(["make", "-C", os.path.join(ROOT, "monocular_slam_amd", "csrc"), "-j4"], check=True, capture_output=True)

@@ -130,3 +130,74 @@ def test_block_diagonal_batch_of_windows(ctx, oracle):
     lo = sum(p["n_points"] for p in parts[:2])
     np.testing.assert_array_equal(g["Hll"][lo:lo + parts[2]["n_points"]], alone["Hll"])
     assert abs(sum(ctx.ba_build(p)["robust_chi2"] for p in parts) - g["robust_chi2"]) <= 1e-9 * g["robust_chi2"]
+
+
+def test_windows_with_their_own_lambda_equal_separate_schur_complements(ctx, oracle):
+    """Four local-BA windows in one block-diagonal plan, a different lambda each (mslam_ba_plan_set_windows +
+    mslam_ba_plan_schur_windows_dev): every window's diagonal block of S / b_s and its landmark updates equal what the window
+    gives alone with its lambda; blocks between windows are zero; per-window chi2 / computeScale sums come back."""
+    parts = [synth.ba_problem(5, 700, 90 + i) for i in range(4)]
+    pr = synth.ba_concat(parts)
+    lams = np.array([1e-3, 2.0, 50.0, 1e3])
+    plan = api.BaPlan(ctx, pr)
+    pose_w = np.concatenate([np.full(q["n_poses"], i, np.int32) for i, q in enumerate(parts)])
+    point_w = np.concatenate([np.full(q["n_points"], i, np.int32) for i, q in enumerate(parts)])
+    plan.set_windows(pose_w, point_w, 4)
+    plan.build_dev()
+    plan.schur_windows_dev(lams)
+    S, bs = plan.download_schur()
+    chi_w, _ = plan.download_window_sums()
+    xp_all = np.zeros(S.shape[0])
+    off = 0
+    for i, q in enumerate(parts):
+        alone = api.BaPlan(ctx, q)
+        alone.build_dev(); alone.schur_dev(float(lams[i]))
+        Sa, ba_ = alone.download_schur()
+        n6 = Sa.shape[0]
+        # (not bit-equal: the 64-point Schur tiles of the concatenated plan straddle window boundaries, so the same terms are
+        # grouped differently -- a fixed grouping per plan, hence still run-to-run identical)
+        np.testing.assert_allclose(S[off:off + n6, off:off + n6], Sa, rtol=1e-12, atol=1e-12 * np.abs(Sa).max())
+        np.testing.assert_allclose(bs[off:off + n6], ba_, rtol=1e-12, atol=1e-12 * np.abs(ba_).max())
+        assert not S[off:off + n6, :off].any() and not S[off:off + n6, off + n6:].any()
+        assert abs(chi_w[i] - alone.download()["robust_chi2"]) <= 1e-12 * chi_w[i]
+        xp_all[off:off + n6] = np.linalg.solve(Sa, ba_)
+        alone.close()
+        off += n6
+    plan.backsub_dev(xp_all, apply_to_points=False)
+    x, sc = plan.download_x()
+    _, sc_w = plan.download_window_sums()
+    assert abs(sc_w.sum() - sc) <= 1e-9 * abs(sc)
+    n6 = S.shape[0]
+    b_l = plan.download()["b"][n6:]
+    xl = x[n6:]
+    lo = 0
+    for i, q in enumerate(parts):
+        n3 = 3 * q["n_points"]
+        ref = np.sum(xl[lo:lo + n3] * (lams[i] * xl[lo:lo + n3] + b_l[lo:lo + n3]))
+        assert abs(sc_w[i] - ref) <= 1e-9 * abs(ref)
+        lo += n3
+    plan.close()
+
+
+def test_duplicate_edges_are_refused_and_wide_tiles_fall_back(ctx):
+    """Two edges between one pose and one point need one accumulated block (g2o adds them): refused with a status instead of
+    a silently wrong system.  A graph whose 64-point tiles see more than 64 free poses has no device Schur path:
+    MSLAM_ERR_CAPACITY tells the caller to run the Schur complement on the host."""
+    pr = synth.ba_problem(4, 60, 3)
+    dup = dict(pr)
+    for k in ("edge_pose", "edge_point", "obs", "info"):
+        dup[k] = np.concatenate([pr[k], pr[k][:1]])
+    dup["n_edges"] = pr["n_edges"] + 1
+    with pytest.raises(api.MslamError) as e:
+        api.BaPlan(ctx, dup)
+    assert e.value.status == api.ERR_INVALID
+    wide = synth.ba_problem(80, 64, 5)
+    if np.bincount(wide["edge_point"][~wide["pose_fixed"][wide["edge_pose"]].astype(bool)], minlength=64).size:
+        plan = api.BaPlan(ctx, wide)
+        plan.build_dev()
+        nfree_seen = len(set(wide["edge_pose"][~wide["pose_fixed"][wide["edge_pose"]].astype(bool)].tolist()))
+        if nfree_seen > 64:
+            with pytest.raises(api.MslamError) as e2:
+                plan.schur_dev(1.0)
+            assert e2.value.status == api.ERR_CAPACITY
+        plan.close()

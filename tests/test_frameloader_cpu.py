@@ -132,3 +132,22 @@ def test_bad_files_fail_loudly(tmp_path):
     (tmp_path / "x.jpg").write_bytes(b"\xff\xd8\xff")
     r = subprocess.run([CHECK, str(tmp_path / "x.jpg"), str(tmp_path / "o.raw")], capture_output=True, text=True)
     assert r.returncode == 1 and "unsupported" in r.stderr
+
+
+def test_hostile_headers_are_refused_before_allocating(tmp_path):
+    """Header dimensions come from the file: absurd sizes, overflowing digit runs and zero sizes fail through the
+    false/err contract instead of allocating gigabytes or overflowing."""
+    import struct, zlib
+
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xFFFFFFFF)
+    png = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", 0x7FFFFFFF, 0x7FFFFFFF, 8, 0, 0, 0, 0)) + \
+        chunk(b"IDAT", zlib.compress(b"\0\0")) + chunk(b"IEND", b"")
+    (tmp_path / "huge.png").write_bytes(png)
+    r = subprocess.run([CHECK, str(tmp_path / "huge.png"), str(tmp_path / "o.raw")], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 1 and "out of range" in r.stderr
+    for name, body in (("digits.pgm", b"P5 99999999999999999999 2 255\n\0\0"), ("zero.pgm", b"P5 0 4 255\n"), ("maxval.pgm", b"P5 2 2 0\n\0\0\0\0"),
+                       ("big.pgm", b"P5 20000 20000 255\n\0")):
+        (tmp_path / name).write_bytes(body)
+        r = subprocess.run([CHECK, str(tmp_path / name), str(tmp_path / "o.raw")], capture_output=True, text=True, timeout=60)
+        assert r.returncode == 1 and r.stderr.strip(), name

@@ -156,3 +156,60 @@ def test_frame_loader_sequence_matches_raw_pipeline(tmp_path, sequence):
                       [2 * qx * qy + 2 * qz * qw, 1 - 2 * qx * qx - 2 * qz * qz, 2 * qy * qz - 2 * qx * qw],
                       [2 * qx * qz - 2 * qy * qw, 2 * qy * qz + 2 * qx * qw, 1 - 2 * qx * qx - 2 * qy * qy]])
         np.testing.assert_allclose(g, np.c_[R, -R @ np.array([tx, ty, tz])], rtol=1e-12, atol=1e-12)  # R kept, t' = -R t (as written)
+
+
+def _write_seq(path, frames, K):
+    n, h, w = frames.shape
+    with open(path, "wb") as f:
+        f.write(struct.pack("<4i", n, w, h, 1))
+        f.write(np.ascontiguousarray(K, np.float64).tobytes())
+        f.write(np.ascontiguousarray(frames).tobytes())
+
+
+def test_batched_pipeline_equals_single_stream_pipelines(tmp_path, sequence):
+    """BatchedPipeline (B sequences per launch, features resident on the device between the stages) gives every stream what
+    the single-stream ProcessingPipeline gives it alone: identical feature counts, poses and map, bit for bit."""
+    frames, gt = sequence
+    seqs = [frames, synth.rigid_sequence(640, 480, 2007, n_frames=4)[0], frames[:, ::-1, :].copy()]
+    flags = ("--no-dist", "--pnp-hyps", "256", "--pnp-thr", "3.0")
+    paths = []
+    for i, fr in enumerate(seqs):
+        p = tmp_path / f"s{i}.bin"
+        _write_seq(p, fr, synth.K_TUM1)
+        paths.append(str(p))
+    out = tmp_path / "batched.txt"
+    demo = os.path.join(ROOT, "monocular_slam_amd", "host", "mslam_batched_demo")
+    r = subprocess.run([demo, str(out), *paths, *flags, "--check-descriptors"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    got = []
+    for line in open(out):
+        tok = line.split()
+        if tok[0] == "stream":
+            got.append(dict(poses=[], nfeat=[], pts=[], desc=None))
+        elif tok[0] == "frame":
+            got[-1]["nfeat"].append(int(tok[2])); got[-1]["poses"].append(np.array(tok[3:], float).reshape(3, 4))
+        elif tok[0] == "descsum":
+            got[-1]["desc"] = (int(tok[1]), int(tok[2]))
+        elif tok[0] != "mappoints":
+            got[-1]["pts"].append([float(v) for v in tok[1:4]] + [int(tok[4])])
+    assert len(got) == 3
+    for i, fr in enumerate(seqs):
+        poses, nfeat, pts, _ = _run_demo(tmp_path, fr, synth.K_TUM1, *flags)
+        assert got[i]["nfeat"] == nfeat
+        for a, b in zip(got[i]["poses"], poses):
+            np.testing.assert_array_equal(a, b)
+        np.testing.assert_array_equal(np.array(got[i]["pts"]), pts)
+        assert got[i]["desc"][0] == nfeat[-1] and got[i]["desc"][1] != 0
+    # the streams really are different problems
+    assert not np.array_equal(got[0]["poses"][2], got[1]["poses"][2])
+
+
+def test_cpp_bench_binary_runs_the_batched_path():
+    """mslam_bench (C++ host, MultiStreamRunner over the C ABI) at a small configuration: valid outputs, one JSON line."""
+    import json
+    exe = os.path.join(ROOT, "monocular_slam_amd", "host", "mslam_bench")
+    r = subprocess.run([exe, "--steps", "2", "--warmup", "1", "--batch", "4", "--sub-batches", "2", "--seq-len", "3", "--w", "640", "--h", "480",
+                        "--nfeatures", "500", "--pnp-points", "400", "--pnp-hyps", "256"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr + r.stdout
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["valid_outputs"] is True and d["value"] > 0 and d["mean_keypoints"] > 400 and d["mean_ratio_survivors"] > 60
