@@ -2,6 +2,7 @@
 // what pipeline_demo gives for each of them alone.  Output: per stream "stream s", then the pipeline_demo lines
 // ("frame i nfeat r00 .. r23", "mappoints M", "id x y z nobs").
 //   batched_demo out.txt in0.bin in1.bin ... [--nfeatures N] [--no-dist] [--pnp-hyps H] [--pnp-thr T] [--check-descriptors]
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <fstream>
@@ -10,14 +11,16 @@
 
 int main(int argc, char** argv)
 {
-    if (argc < 3) { std::fprintf(stderr, "usage: %s out.txt in0.bin [in1.bin ...] [--nfeatures N] [--no-dist] [--pnp-hyps H] [--pnp-thr T] [--check-descriptors]\n", argv[0]); return 2; }
+    if (argc < 3) { std::fprintf(stderr, "usage: %s out.txt in0.bin [in1.bin ...] [--nfeatures N] [--no-dist] [--pnp-hyps H] [--pnp-thr T] [--check-descriptors] [--replicate R] [--time]\n", argv[0]); return 2; }
     std::vector<const char*> inputs;
-    bool nodist = false, checkDesc = false;
-    int nfeatures = 500, pnpH = 100;
+    bool nodist = false, checkDesc = false, timeit = false;
+    int nfeatures = 500, pnpH = 100, replicate = 1;
     double pnpThr = 8.0;
     for (int i = 2; i < argc; i++) {
         if (!std::strcmp(argv[i], "--no-dist")) nodist = true;
         else if (!std::strcmp(argv[i], "--check-descriptors")) checkDesc = true;
+        else if (!std::strcmp(argv[i], "--time")) timeit = true;
+        else if (!std::strcmp(argv[i], "--replicate") && i + 1 < argc) replicate = std::atoi(argv[++i]);
         else if (!std::strcmp(argv[i], "--nfeatures") && i + 1 < argc) nfeatures = std::atoi(argv[++i]);
         else if (!std::strcmp(argv[i], "--pnp-hyps") && i + 1 < argc) pnpH = std::atoi(argv[++i]);
         else if (!std::strcmp(argv[i], "--pnp-thr") && i + 1 < argc) pnpThr = std::atof(argv[++i]);
@@ -49,13 +52,34 @@ int main(int argc, char** argv)
             if (!in) { std::fprintf(stderr, "short read on %s\n", path); return 2; }
             dms.push_back(own.back().get());
         }
+        // --replicate R: every input sequence R times (independent DataManagers): more streams per launch for timing
+        const size_t n_in = own.size();
+        for (int r = 1; r < replicate; r++)
+            for (size_t s = 0; s < n_in; s++) {
+                own.emplace_back(new DataManager());
+                own.back()->frames = own[s]->frames;
+                for (Frame& f : own.back()->frames) { f.frameBuffer = f.frameBuffer.clone(); f.K = f.K.clone(); }
+                dms.push_back(own.back().get());
+            }
         FeatureExtractor fe;
         fe.params.nfeatures = nfeatures;
         CameraPoseEstimator cpe;
         cpe.pnpHypotheses = pnpH; cpe.pnp.reproj_thr = pnpThr;
         if (nodist) for (double& d : cpe.distCoeff) d = 0.0;
         BatchedPipeline slam(dms, fe, cpe);
-        for (int i = 0; i < n; i++) slam.process(i);
+        std::vector<double> tick_ms;
+        for (int i = 0; i < n; i++) {
+            const auto t0 = std::chrono::steady_clock::now();
+            slam.process(i);
+            tick_ms.push_back(1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+        }
+        if (timeit) {
+            std::printf("{\"streams\": %zu, \"frames\": %d, \"tick_ms\": [", dms.size(), n);
+            for (size_t i = 0; i < tick_ms.size(); i++) std::printf("%s%.3f", i ? ", " : "", tick_ms[i]);
+            double tail = 0; int cnt = 0;
+            for (size_t i = 2; i < tick_ms.size(); i++) { tail += tick_ms[i]; cnt++; }
+            std::printf("], \"tracking_frames_per_s\": %.1f}\n", cnt ? 1e3 * dms.size() * cnt / tail : 0.0);
+        }
         FILE* out = std::fopen(argv[1], "w");
         if (!out) { std::fprintf(stderr, "cannot write %s\n", argv[1]); return 2; }
         for (size_t s = 0; s < dms.size(); s++) {
