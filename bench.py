@@ -151,6 +151,12 @@ def main():
     from monocular_slam_amd import api
     from monocular_slam_amd.tracking import TrackingBatch
     api.lib()
+    rccl_path = None
+    if world > 1 or args.force_collective:
+        try:
+            rccl_path = api.comm_preload()   # the RCCL beside this library's HIP runtime, before torch brings its own copies
+        except api.MslamError as e:
+            rccl_path = "unavailable: %s" % e
     dist = None
     if world > 1:
         import torch
@@ -192,9 +198,9 @@ def main():
                 uid = bytes(t.tolist())
             comm = api.Comm(tbs[0].pnp_ctx, uid, rank, world)
             tbs[0].set_comm(comm)
-            collective.update(backend="rccl (mslam_comm_allgather_i32_dev, on the PnP stream)", **comm.info())
+            collective.update(backend="rccl (mslam_comm_allgather_i32_dev, on the PnP stream)", library=rccl_path, **comm.info())
         except api.MslamError as e:   # e.g. several rehearsal ranks on one device: RCCL refuses duplicate GPUs
-            collective.update(backend="gloo (host, once per step) -- RCCL communicator unavailable", error=str(e)[:300])
+            collective.update(backend="gloo (host, once per step) -- RCCL communicator unavailable", library=rccl_path, error=str(e)[:300])
 
     def gloo_gather_fallback():
         if collective is not None and tbs[0].comm is None and world > 1:

@@ -370,6 +370,10 @@ int mslam_argmax_counts(const int32_t* counts, int n, int* best, int* best_count
  * an RCCL call fails. */
 #define MSLAM_COMM_ID_BYTES 128
 typedef struct mslam_comm mslam_comm;
+/* Binds RCCL now (optional; the first communicator does it otherwise): the librccl.so.1 beside the libamdhip64 this library
+ * is linked to, by absolute path -- a process that also holds another ROCm stack under the same SONAMEs (a PyTorch wheel)
+ * should call this BEFORE loading that stack.  path_out (optional) receives the file that was bound. */
+int mslam_comm_preload(char* path_out, int cap);
 int mslam_comm_unique_id(uint8_t id[MSLAM_COMM_ID_BYTES]);
 int mslam_comm_create(mslam_ctx* ctx, const uint8_t id[MSLAM_COMM_ID_BYTES], int rank, int nranks, mslam_comm** out);
 int mslam_comm_info(mslam_comm* comm, int* rank, int* nranks, int* rccl_version);

@@ -530,6 +530,15 @@ class PinnedBuf:
             pass
 
 
+def comm_preload() -> str:
+    """Bind this library's RCCL (the one beside its HIP runtime) now; call before importing torch.  Returns the path."""
+    buf = C.create_string_buffer(512)
+    rc = lib().mslam_comm_preload(buf, 512)
+    if rc != OK:
+        raise MslamError(rc, "mslam_comm_preload", lib().mslam_strerror(rc).decode())
+    return buf.value.decode()
+
+
 class Comm:
     """One rank of the RCCL communicator behind mslam_comm_* (one process per GPU)."""
 

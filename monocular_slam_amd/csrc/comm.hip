@@ -18,6 +18,8 @@
 #include <dlfcn.h>
 #include <cstring>
 #include <mutex>
+#include <string>
+#include <vector>
 
 namespace {
 
@@ -32,7 +34,7 @@ struct Rccl {
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
-    std::string err;
+    std::string err, path;
 };
 
 Rccl g_rccl;
@@ -42,9 +44,21 @@ bool rccl_load()
 {
     std::lock_guard<std::mutex> lk(g_rccl_mu);
     if (g_rccl.h) return true;
-    const char* names[] = { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" };
+    // The RCCL that belongs to THIS library's HIP runtime: the librccl.so.1 that sits beside the libamdhip64 this library
+    // is bound to, by absolute path.  A process may hold a second ROCm stack (a PyTorch wheel bundles its own libamdhip64 and
+    // librccl under the same SONAMEs); binding by name would pick whichever was loaded first, and an RCCL running on the other
+    // HIP runtime cannot use this runtime's streams or device pointers.  RTLD_NOW | RTLD_DEEPBIND: its own symbols first, bound now.
+    std::vector<std::string> names;
+    Dl_info info;
+    if (dladdr(reinterpret_cast<void*>(&hipGetDeviceCount), &info) && info.dli_fname) {
+        std::string dir(info.dli_fname);
+        const size_t slash = dir.rfind('/');
+        if (slash != std::string::npos) names.push_back(dir.substr(0, slash) + "/librccl.so.1");
+    }
+    names.push_back("/opt/rocm/lib/librccl.so.1");
+    names.push_back("librccl.so.1");
     void* h = nullptr;
-    for (const char* n : names) { h = dlopen(n, RTLD_NOW | RTLD_LOCAL); if (h) break; }
+    for (const std::string& n : names) { h = dlopen(n.c_str(), RTLD_NOW | RTLD_LOCAL | RTLD_DEEPBIND); if (h) { g_rccl.path = n; break; } }
     if (!h) { g_rccl.err = std::string("dlopen librccl: ") + (dlerror() ? dlerror() : "not found"); return false; }
 #define SYM(field, name) \
     *reinterpret_cast<void**>(&g_rccl.field) = dlsym(h, name); \
@@ -81,6 +95,13 @@ struct AllComm { std::vector<int> devs; std::vector<ncclComm_t> comms; };
 static std::vector<AllComm> g_all;
 
 extern "C" {
+
+int mslam_comm_preload(char* path_out, int cap)
+{
+    if (!rccl_load()) return MSLAM_ERR_NO_DEVICE;
+    if (path_out && cap > 0) { std::strncpy(path_out, g_rccl.path.c_str(), (size_t)cap - 1); path_out[cap - 1] = 0; }
+    return MSLAM_OK;
+}
 
 int mslam_comm_unique_id(uint8_t id[MSLAM_COMM_ID_BYTES])
 {

@@ -9,7 +9,7 @@ import json
 import sys
 
 summ = json.load(open(sys.argv[1]))
-out = {"_batch": 32, "_source": "profiles/r01_pmc_summary_default_bench.json (tools/profile.sh + tools/summarize_pmc.py)", "_formula": "(2*FETCH_SIZE + WRITE_SIZE) * 1024 bytes, averages per dispatch, bench default batch 32",
+out = {"_batch": 32, "_source": "%s (tools/profile.sh + tools/summarize_pmc.py)" % sys.argv[1], "_formula": "(2*FETCH_SIZE + WRITE_SIZE) * 1024 bytes, averages per dispatch, bench default batch 32",
        "_calibration": {"read_1GiB_FETCH_SIZE_KiB": {"4B_per_lane": 524299.5, "16B_per_lane": 524298.5, "1B_per_lane_256MiB": 131082.0}}}
 for k, v in summ.items():
     if "FETCH_SIZE" in v and "WRITE_SIZE" in v and not k.startswith("__amd"):

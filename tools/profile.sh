@@ -7,7 +7,7 @@
 set -e
 OUT=${1:-gpurun_out/prof}
 shift || true
-ARGS=${@:---steps 5 --warmup 2 --cpu-frames 0}
+ARGS=${@:---steps 3 --warmup 1 --cpu-frames 0 --no-ingest --no-parity}
 REPO=$(pwd)
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
