@@ -248,6 +248,14 @@ int mslam_triangulate(mslam_ctx* ctx, const double* x1, const double* x2, int n,
                       const double Rt1[12], const double Rt2[12], const double K1[9], const double K2[9],
                       double* X, uint8_t* front, int* n_front);
 
+/* G independent groups in one launch sequence (host pointers, synchronous): group g holds points [ofs[g], ofs[g+1]) of
+ * x1/x2/X/front (ofs[0] = 0) and its own cameras Rt1/Rt2 (G x 12), K1/K2 (G x 9); n_front: G counts (optional).  Point for
+ * point the same arithmetic as mslam_triangulate.  What the batched stages use for the four-candidate cheirality vote
+ * (:337-354) and the new-point triangulation (:488-512) of B streams at once. */
+int mslam_triangulate_batch(mslam_ctx* ctx, const double* x1, const double* x2, const int32_t* ofs, int G,
+                            const double* Rt1, const double* Rt2, const double* K1, const double* K2,
+                            double* X, uint8_t* front, int32_t* n_front);
+
 /* ---- R14-R17: bundle-adjustment linearisation ----------------------------------------
  * Stands in for one pass of g2o's BlockSolver<6,3>::buildSystem
  * (ThirdParty/g2o/g2o/core/block_solver.hpp:502-560) over the graph that

@@ -415,6 +415,18 @@ def _ctx_methods():
                     "mslam_triangulate")
         return X, front, nf.value
 
+    def triangulate_batch(self, x1, x2, ofs, Rt1, Rt2, K1, K2):
+        """mslam_triangulate_batch: G groups (points ofs[g]..ofs[g+1]) with their own cameras in one launch."""
+        x1 = np.ascontiguousarray(x1, np.float64); x2 = np.ascontiguousarray(x2, np.float64)
+        ofs = np.ascontiguousarray(ofs, np.int32)
+        G, N = ofs.size - 1, int(ofs[-1])
+        a = [np.ascontiguousarray(m, np.float64) for m in (Rt1, Rt2, K1, K2)]
+        X = np.zeros((N, 3)); front = np.zeros(max(N, 1), np.uint8); nf = np.zeros(G, np.int32)
+        self._check(lib().mslam_triangulate_batch(self._h, _p(x1, f64p), _p(x2, f64p), _p(ofs, i32p), G, _p(a[0], f64p), _p(a[1], f64p),
+                                                  _p(a[2], f64p), _p(a[3], f64p), _p(X, f64p), _p(front, u8p), _p(nf, i32p)),
+                    "mslam_triangulate_batch")
+        return X, front[:N], nf
+
     def fmat_ransac8_batch_dev(self, x1_ptr, x2_ptr, M_ptr, capM, samples_ptr, H, B, params, F_ptr, status_ptr,
                                counts_ptr, best_ptr, ninl_ptr):
         self._check(lib().mslam_fmat_ransac8_batch_dev(self._h, vp(x1_ptr), vp(x2_ptr), vp(M_ptr), capM, vp(samples_ptr), H, B,
@@ -442,7 +454,7 @@ def _ctx_methods():
         a.update(robust_chi2=ss.robust_chi2, n_free_poses=ss.n_free_poses, nnzb=ss.nnzb)
         return a
 
-    for f in (fmat_ransac8, pnp_ransac, triangulate, fmat_ransac8_batch_dev, pnp_ransac_batch_dev, ba_build):
+    for f in (fmat_ransac8, pnp_ransac, triangulate, triangulate_batch, fmat_ransac8_batch_dev, pnp_ransac_batch_dev, ba_build):
         setattr(Context, f.__name__, f)
 
 

@@ -1265,39 +1265,66 @@ void pnp_finalize_k(PnpArgs a)
 // ------------------------------------------------------------------ triangulation (R11)
 struct TriArgs { const double* x1; const double* x2; int n; double P1[12], P2[12], Rt1[12], Rt2[12]; double* X; uint8_t* front; int32_t* n_front; };
 
-// symmetric 4x4 Jacobi in registers is awkward; the 4x4 problem is done per lane in scratch memory
+// symmetric 4x4 Jacobi in registers is awkward; the 4x4 problem is done per lane in scratch memory.
+// One point: DLT rows x P3 - P1, y P3 - P2 of both views, null vector of A^T A, dehomogenise, z > 0 in both cameras.
+__device__ __forceinline__ bool tri_point(const double* __restrict__ P1, const double* __restrict__ P2, const double* __restrict__ Rt1,
+                                          const double* __restrict__ Rt2, const double* __restrict__ x1, const double* __restrict__ x2, int p,
+                                          double* __restrict__ Xout)
+{
+    double A[16];
+    for (int j = 0; j < 4; j++) {
+        A[0 * 4 + j] = P1[0 * 4 + j] - P1[2 * 4 + j] * x1[2 * p];
+        A[1 * 4 + j] = P1[1 * 4 + j] - P1[2 * 4 + j] * x1[2 * p + 1];
+        A[2 * 4 + j] = P2[0 * 4 + j] - P2[2 * 4 + j] * x2[2 * p];
+        A[3 * 4 + j] = P2[1 * 4 + j] - P2[2 * 4 + j] * x2[2 * p + 1];
+    }
+    double AtA[16], w[4], V[16];
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++) {
+            double acc = 0;
+            for (int k = 0; k < 4; k++) acc += A[k * 4 + i] * A[k * 4 + j];
+            AtA[i * 4 + j] = acc;
+        }
+    jacobi_mem(AtA, 4, w, V);
+    const int k0 = argmin_first(w, 4);
+    const double Xh[4] = { V[0 * 4 + k0], V[1 * 4 + k0], V[2 * 4 + k0], V[3 * 4 + k0] };
+    const double X0 = Xh[0] / Xh[3], X1 = Xh[1] / Xh[3], X2 = Xh[2] / Xh[3];
+    Xout[3 * p] = X0; Xout[3 * p + 1] = X1; Xout[3 * p + 2] = X2;
+    const double z1 = Rt1[8] * X0 + Rt1[9] * X1 + Rt1[10] * X2 + Rt1[11];
+    const double z2 = Rt2[8] * X0 + Rt2[9] * X1 + Rt2[10] * X2 + Rt2[11];
+    return z1 > 0 && z2 > 0;
+}
+
 __global__ __launch_bounds__(64)
 void triangulate_k(TriArgs a)
 {
     const int p = blockIdx.x * 64 + threadIdx.x;
     bool f = false;
     if (p < a.n) {
-        double A[16];
-        for (int j = 0; j < 4; j++) {
-            A[0 * 4 + j] = a.P1[0 * 4 + j] - a.P1[2 * 4 + j] * a.x1[2 * p];
-            A[1 * 4 + j] = a.P1[1 * 4 + j] - a.P1[2 * 4 + j] * a.x1[2 * p + 1];
-            A[2 * 4 + j] = a.P2[0 * 4 + j] - a.P2[2 * 4 + j] * a.x2[2 * p];
-            A[3 * 4 + j] = a.P2[1 * 4 + j] - a.P2[2 * 4 + j] * a.x2[2 * p + 1];
-        }
-        double AtA[16], w[4], V[16];
-        for (int i = 0; i < 4; i++)
-            for (int j = 0; j < 4; j++) {
-                double acc = 0;
-                for (int k = 0; k < 4; k++) acc += A[k * 4 + i] * A[k * 4 + j];
-                AtA[i * 4 + j] = acc;
-            }
-        jacobi_mem(AtA, 4, w, V);
-        const int k0 = argmin_first(w, 4);
-        const double Xh[4] = { V[0 * 4 + k0], V[1 * 4 + k0], V[2 * 4 + k0], V[3 * 4 + k0] };
-        const double X0 = Xh[0] / Xh[3], X1 = Xh[1] / Xh[3], X2 = Xh[2] / Xh[3];
-        a.X[3 * p] = X0; a.X[3 * p + 1] = X1; a.X[3 * p + 2] = X2;
-        double z1 = a.Rt1[8] * X0 + a.Rt1[9] * X1 + a.Rt1[10] * X2 + a.Rt1[11];
-        double z2 = a.Rt2[8] * X0 + a.Rt2[9] * X1 + a.Rt2[10] * X2 + a.Rt2[11];
-        f = z1 > 0 && z2 > 0;
+        f = tri_point(a.P1, a.P2, a.Rt1, a.Rt2, a.x1, a.x2, p, a.X);
         if (a.front) a.front[p] = (uint8_t)f;
     }
     unsigned long long bal = __ballot(f);
     if (threadIdx.x == 0 && bal) atomicAdd(a.n_front, __popcll(bal));
+}
+
+// G groups per launch: group g = points [ofs[g], ofs[g+1]) with its own cameras cam[g] = {P1, P2, Rt1, Rt2} (48 doubles)
+__global__ __launch_bounds__(64)
+void triangulate_groups_k(const double* __restrict__ x1, const double* __restrict__ x2, const int32_t* __restrict__ ofs,
+                          const double* __restrict__ cam, double* __restrict__ X, uint8_t* __restrict__ front, int32_t* __restrict__ n_front)
+{
+    const int g = blockIdx.y;
+    const int p0 = ofs[g], n = ofs[g + 1] - p0;
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (blockIdx.x * 64 >= n) return;
+    bool f = false;
+    if (i < n) {
+        const double* c = cam + (size_t)g * 48;
+        f = tri_point(c, c + 12, c + 24, c + 36, x1, x2, p0 + i, X);
+        if (front) front[p0 + i] = (uint8_t)f;
+    }
+    unsigned long long bal = __ballot(f);
+    if (threadIdx.x == 0 && bal) atomicAdd(n_front + g, __popcll(bal));
 }
 
 // smallest double t with sqrt(t) >= thr, so that (sqrt(d2) < thr) == (d2 < t) for every d2
@@ -1515,6 +1542,53 @@ int mslam_triangulate(mslam_ctx* ctx, const double* x1, const double* x2, int n,
     HIP_TRY(ctx, hipMemcpyAsync(&hn, base + o_n, 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
     if (n_front) *n_front = hn;
+    return MSLAM_OK;
+}
+
+int mslam_triangulate_batch(mslam_ctx* ctx, const double* x1, const double* x2, const int32_t* ofs, int G, const double* Rt1,
+                            const double* Rt2, const double* K1, const double* K2, double* X, uint8_t* front, int32_t* n_front)
+{
+    if (!ctx || !x1 || !x2 || !ofs || G < 1 || !Rt1 || !Rt2 || !K1 || !K2 || !X || ofs[0] != 0) return MSLAM_ERR_INVALID;
+    int max_n = 0;
+    for (int g = 0; g < G; g++) { const int n = ofs[g + 1] - ofs[g]; if (n < 0) return MSLAM_ERR_INVALID; max_n = n > max_n ? n : max_n; }
+    const int N = ofs[G];
+    if (n_front) for (int g = 0; g < G; g++) n_front[g] = 0;
+    if (N == 0) return MSLAM_OK;
+    MSLAM_TRY(ctx_set_device(ctx));
+    size_t bytes = 0;
+    auto reserve = [&](size_t m) { bytes = align_up(bytes, 256); size_t o = bytes; bytes += m; return o; };
+    const size_t o_x1 = reserve(sizeof(double) * 2 * N), o_x2 = reserve(sizeof(double) * 2 * N), o_X = reserve(sizeof(double) * 3 * N),
+                 o_f = reserve(N), o_n = reserve(sizeof(int32_t) * G), o_ofs = reserve(sizeof(int32_t) * (G + 1)), o_cam = reserve(sizeof(double) * 48 * G);
+    void* stg = nullptr;
+    MSLAM_TRY(ctx_stage(ctx, bytes, &stg));
+    char* base = (char*)stg;
+    hipStream_t st = ctx->stream;
+    std::vector<double> cam((size_t)G * 48);
+    for (int g = 0; g < G; g++) {
+        double* c = &cam[(size_t)g * 48];
+        const double *k1 = K1 + 9 * g, *k2 = K2 + 9 * g, *r1 = Rt1 + 12 * g, *r2 = Rt2 + 12 * g;
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 4; j++) { // P = K * Rt (:91), the same operation order as mslam_triangulate
+                double p1 = 0, p2 = 0;
+                for (int k = 0; k < 3; k++) { p1 += k1[i * 3 + k] * r1[k * 4 + j]; p2 += k2[i * 3 + k] * r2[k * 4 + j]; }
+                c[i * 4 + j] = p1; c[12 + i * 4 + j] = p2;
+            }
+        for (int i = 0; i < 12; i++) { c[24 + i] = r1[i]; c[36 + i] = r2[i]; }
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(base + o_x1, x1, sizeof(double) * 2 * N, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(base + o_x2, x2, sizeof(double) * 2 * N, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(base + o_ofs, ofs, sizeof(int32_t) * (G + 1), hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(base + o_cam, cam.data(), sizeof(double) * 48 * G, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemsetAsync(base + o_n, 0, sizeof(int32_t) * G, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));   // `cam` is a local
+    LAUNCH(ctx, K_TRIANGULATE, triangulate_groups_k, dim3((max_n + 63) / 64, G), dim3(64), 0, (const double*)(base + o_x1), (const double*)(base + o_x2),
+           (const int32_t*)(base + o_ofs), (const double*)(base + o_cam), (double*)(base + o_X), front ? (uint8_t*)(base + o_f) : (uint8_t*)nullptr,
+           (int32_t*)(base + o_n));
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(X, base + o_X, sizeof(double) * 3 * N, hipMemcpyDeviceToHost, st));
+    if (front) HIP_TRY(ctx, hipMemcpyAsync(front, base + o_f, N, hipMemcpyDeviceToHost, st));
+    if (n_front) HIP_TRY(ctx, hipMemcpyAsync(n_front, base + o_n, sizeof(int32_t) * G, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
     return MSLAM_OK;
 }
 

@@ -1,9 +1,24 @@
 #include "BatchedPipeline.h"
+#include <atomic>
 #include <cstring>
 #include <stdexcept>
+#include <thread>
 #include "Geometry.h"
 
 namespace {
+
+// run fn(b) for b in [0, n) on the host cores: the per-stream preparation between two batched launches (sample tables,
+// coordinate gathers) is independent per stream
+template <typename F> void parallelStreams(int n, F fn)
+{
+    const unsigned hw = std::thread::hardware_concurrency();
+    const int nt = (int)std::min<unsigned>(std::min<unsigned>(hw ? hw : 1u, 16u), (unsigned)n);
+    if (nt <= 1) { for (int b = 0; b < n; b++) fn(b); return; }
+    std::atomic<int> next(0);
+    std::vector<std::thread> th;
+    for (int t = 0; t < nt; t++) th.emplace_back([&]() { for (int b = next++; b < n; b = next++) fn(b); });
+    for (std::thread& t : th) t.join();
+}
 
 void chk(int status, const char* what)
 {
@@ -132,9 +147,9 @@ void BatchedPipeline::fmatAll(const std::vector<const Frame*>& fq, const std::ve
     std::vector<double> x1((size_t)B * capM * 2, 0.0), x2((size_t)B * capM * 2, 0.0);
     std::vector<int32_t> M((size_t)B, 0), S((size_t)B * H * 8, 0);
     rc.assign((size_t)B, MSLAM_OK);
-    for (int b = 0; b < B; b++) {
+    parallelStreams(B, [&](int b) {
         const int m = ms.count[(size_t)b];
-        if (m < 8) { rc[(size_t)b] = MSLAM_ERR_TOO_FEW; continue; }   // the kernels see M = 0 for this stream and skip it
+        if (m < 8) { rc[(size_t)b] = MSLAM_ERR_TOO_FEW; return; }   // the kernels see M = 0 for this stream and skip it
         M[(size_t)b] = m;
         for (int i = 0; i < m; i++) {
             const Point2d& a = fq[(size_t)b]->features.positions[(size_t)ms.query[(size_t)b * cap + i]];
@@ -144,7 +159,7 @@ void BatchedPipeline::fmatAll(const std::vector<const Frame*>& fq, const std::ve
         }
         const std::vector<int32_t> t = geom::sampleTable(m, H, 8, seeds[(size_t)b]);
         std::memcpy(&S[(size_t)b * H * 8], t.data(), sizeof(int32_t) * t.size());
-    }
+    });
     mslam_ctx* ctx = runner_->ctx();
     const size_t nx = sizeof(double) * (size_t)B * capM * 2, nS = sizeof(int32_t) * (size_t)B * H * 8;
     auto up256 = [](size_t v) { return (v + 255) & ~(size_t)255; };
@@ -188,42 +203,69 @@ void BatchedPipeline::poseInitial(int frameIdx)
     std::vector<std::vector<uint8_t>> status;
     std::vector<int> rc;
     fmatAll(fq, ft, ms, seeds, F, status, rc);
+    // per stream: inlier coordinates and the four (R, t) candidates in the reference's order (R1|t1, R1|t2, R2|t1, R2|t2);
+    // ONE batched triangulation for all 4 B candidate groups, then the vote per stream (:337-354)
+    struct Init { bool ok = false; std::vector<double> x1, x2; double K1[9], K2[9], cand[4][12]; };
+    std::vector<Init> in((size_t)B);
+    const double I34[12] = { 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0 };
     for (int b = 0; b < B; b++) {
         DataManager& data = *dms_[(size_t)b];
         Frame& cur = data.frames[(size_t)frameIdx];
         Frame& pre = data.frames[(size_t)frameIdx - 1];
         cur.Rt = pre.Rt.clone(); // kept if the geometry below cannot be estimated
         if (rc[(size_t)b] != MSLAM_OK) { lastStatus[(size_t)b] = rc[(size_t)b]; continue; }
+        Init& s0 = in[(size_t)b];
         const int m = ms.count[(size_t)b];
-        std::vector<double> x1, x2;
         for (int i = 0; i < m; i++)
             if (status[(size_t)b][(size_t)i]) {
                 const Point2d& a = pre.features.positions[(size_t)ms.query[(size_t)b * cap + i]];
                 const Point2d& c = cur.features.positions[(size_t)ms.train[(size_t)b * cap + i]];
-                x1.push_back(a.x); x1.push_back(a.y); x2.push_back(c.x); x2.push_back(c.y);
+                s0.x1.push_back(a.x); s0.x1.push_back(a.y); s0.x2.push_back(c.x); s0.x2.push_back(c.y);
             }
-        const int ng = (int)x1.size() / 2;
-        double K1[9], K2[9], E[9], R[2][9], t[2][3];
-        matTo(pre.K, K1, 9); matTo(cur.K, K2, 9);
-        geom::essentialFromF(&F[(size_t)b * 9], K1, K2, E);
+        double E[9], R[2][9], t[2][3];
+        matTo(pre.K, s0.K1, 9); matTo(cur.K, s0.K2, 9);
+        geom::essentialFromF(&F[(size_t)b * 9], s0.K1, s0.K2, E);
         geom::extractRTfromE(E, R, t);
-        const double I34[12] = { 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0 };
-        std::vector<double> X((size_t)ng * 3), bestX;
-        int bestIdx = -1, maxCount = -1;
-        double bestRt[12];
-        for (int c = 0; c < 4; c++) {   // candidates in the reference's order; most points in front wins (:337-354)
-            double cand[12];
-            for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) cand[i * 4 + j] = R[c / 2][i * 3 + j]; cand[i * 4 + 3] = t[c % 2][i]; }
-            int count = 0;
-            chk(mslam_triangulate(runner_->ctx(), x1.data(), x2.data(), ng, I34, cand, K1, K2, X.data(), nullptr, &count), "mslam_triangulate");
-            if (maxCount < count) { maxCount = count; bestIdx = c; std::memcpy(bestRt, cand, sizeof(cand)); bestX = X; }
+        for (int c = 0; c < 4; c++)
+            for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) s0.cand[c][i * 4 + j] = R[c / 2][i * 3 + j]; s0.cand[c][i * 4 + 3] = t[c % 2][i]; }
+        s0.ok = true;
+    }
+    std::vector<double> gx1, gx2, gRt1, gRt2, gK1, gK2;
+    std::vector<int32_t> ofs(1, 0), gstream;
+    for (int b = 0; b < B; b++) {
+        if (!in[(size_t)b].ok) continue;
+        const Init& s0 = in[(size_t)b];
+        for (int c = 0; c < 4; c++) {
+            gx1.insert(gx1.end(), s0.x1.begin(), s0.x1.end()); gx2.insert(gx2.end(), s0.x2.begin(), s0.x2.end());
+            gRt1.insert(gRt1.end(), I34, I34 + 12); gRt2.insert(gRt2.end(), s0.cand[c], s0.cand[c] + 12);
+            gK1.insert(gK1.end(), s0.K1, s0.K1 + 9); gK2.insert(gK2.end(), s0.K2, s0.K2 + 9);
+            ofs.push_back(ofs.back() + (int32_t)(s0.x1.size() / 2));
+            gstream.push_back(b);
         }
+    }
+    const int G = (int)gstream.size();
+    std::vector<double> gX((size_t)ofs.back() * 3);
+    std::vector<int32_t> gfront((size_t)std::max(G, 1), 0);
+    if (G > 0 && ofs.back() > 0)
+        chk(mslam_triangulate_batch(runner_->ctx(), gx1.data(), gx2.data(), ofs.data(), G, gRt1.data(), gRt2.data(), gK1.data(), gK2.data(), gX.data(), nullptr,
+                                    gfront.data()), "mslam_triangulate_batch");
+    for (int g0 = 0; g0 < G; g0 += 4) {
+        const int b = gstream[(size_t)g0];
+        DataManager& data = *dms_[(size_t)b];
+        Frame& cur = data.frames[(size_t)frameIdx];
+        Frame& pre = data.frames[(size_t)frameIdx - 1];
+        const Init& s0 = in[(size_t)b];
+        int bestIdx = -1, maxCount = -1;
+        for (int c = 0; c < 4; c++)
+            if (maxCount < gfront[(size_t)g0 + c]) { maxCount = gfront[(size_t)g0 + c]; bestIdx = c; }
         if (bestIdx < 0) { lastStatus[(size_t)b] = MSLAM_ERR_DEGENERATE; continue; }
+        const double* bestX = gX.data() + (size_t)ofs[(size_t)g0 + bestIdx] * 3;
         double preRt[12], out[12];
         matTo(pre.Rt, preRt, 12);
-        geom::concatenateRts(preRt, bestRt, out);
+        geom::concatenateRts(preRt, s0.cand[bestIdx], out);
         cur.Rt = matFrom(out, 3, 4);
         int count = 0;
+        const int m = ms.count[(size_t)b];
         for (int i = 0; i < m; i++)
             if (status[(size_t)b][(size_t)i] == 1) {
                 registerNewMapPoint(data, Point3d(bestX[3 * (size_t)count], bestX[3 * (size_t)count + 1], bestX[3 * (size_t)count + 2]), pre,
@@ -320,39 +362,57 @@ void BatchedPipeline::posePnp(int frameIdx)
         if (best[(size_t)b] >= 0 && ninl[(size_t)b] >= cpe_.pnp.min_inliers) dms_[(size_t)b]->frames[(size_t)frameIdx].Rt = matFrom(&Rt[(size_t)b * 12], 3, 4);
         else lastStatus[(size_t)b] = MSLAM_ERR_DEGENERATE;
     }
-    // ---- triangulate the matches not yet tied to a map point, against each previous frame (:488-512)
-    for (int b = 0; b < B; b++) {
-        DataManager& data = *dms_[(size_t)b];
-        Frame& cur = data.frames[(size_t)frameIdx];
-        Features& curF = cur.features;
-        double curRt[12], curK[9];
-        matTo(cur.Rt, curRt, 12); matTo(cur.K, curK, 9);
-        for (int i = frameIdx - 1; i >= 0 && i >= frameIdx - cpe_.numBackTraverse; i--) {
+    // ---- triangulate the matches not yet tied to a map point, against each previous frame (:488-512): per back frame one
+    // batched call over the streams (the association state of a stream advances from one back frame to the next, so the
+    // back frames stay sequential)
+    for (int i = frameIdx - 1; i >= 0 && i >= frameIdx - cpe_.numBackTraverse; i--) {
+        const size_t mi = (size_t)(frameIdx - 1 - i);
+        std::vector<double> gx1, gx2, gRt1, gRt2, gK1, gK2;
+        std::vector<int32_t> ofs(1, 0), gstream;
+        std::vector<std::vector<std::pair<int, int>>> gpairs;
+        for (int b = 0; b < B; b++) {
+            if (mi >= ps[(size_t)b].cachedMatches.size()) continue;   // this stream left the loop earlier (:456)
+            DataManager& data = *dms_[(size_t)b];
+            Frame& cur = data.frames[(size_t)frameIdx];
             Frame& pre = data.frames[(size_t)i];
+            Features& curF = cur.features;
             Features& preF = pre.features;
-            const size_t mi = (size_t)(frameIdx - 1 - i);
-            if (mi >= ps[(size_t)b].cachedMatches.size()) break;
-            const std::vector<cv::DMatch>& matches = ps[(size_t)b].cachedMatches[mi];
-            std::vector<double> x1, x2;
             std::vector<std::pair<int, int>> pairs;
-            for (const cv::DMatch& m : matches) {
+            const size_t x0 = gx1.size();
+            for (const cv::DMatch& m : ps[(size_t)b].cachedMatches[mi]) {
                 const int cf = m.queryIdx, pf = m.trainIdx;
+                // both ends unassociated; a feature associated earlier in THIS loop is skipped like in the reference,
+                // where the test runs after each registerNewMapPoint
                 if (preF.mapPointsIndices[(size_t)pf] == -1 && curF.mapPointsIndices[(size_t)cf] == -1) {
                     bool dup = false;
                     for (const auto& pr : pairs) dup |= (pr.first == pf || pr.second == cf);
                     if (dup) continue;
                     pairs.push_back({ pf, cf });
-                    x1.push_back(preF.positions[(size_t)pf].x); x1.push_back(preF.positions[(size_t)pf].y);
-                    x2.push_back(curF.positions[(size_t)cf].x); x2.push_back(curF.positions[(size_t)cf].y);
+                    gx1.push_back(preF.positions[(size_t)pf].x); gx1.push_back(preF.positions[(size_t)pf].y);
+                    gx2.push_back(curF.positions[(size_t)cf].x); gx2.push_back(curF.positions[(size_t)cf].y);
                 }
             }
-            if (pairs.empty()) continue;
-            double preRt[12], preK[9];
-            matTo(pre.Rt, preRt, 12); matTo(pre.K, preK, 9);
-            std::vector<double> Xn(pairs.size() * 3);
-            chk(mslam_triangulate(runner_->ctx(), x1.data(), x2.data(), (int)pairs.size(), preRt, curRt, preK, curK, Xn.data(), nullptr, nullptr), "mslam_triangulate");
-            for (size_t k = 0; k < pairs.size(); k++)
-                registerNewMapPoint(data, Point3d(Xn[3 * k], Xn[3 * k + 1], Xn[3 * k + 2]), pre, pairs[k].first, cur, pairs[k].second);
+            if (pairs.empty()) { gx1.resize(x0); gx2.resize(x0); continue; }
+            double m12[12], k9[9];
+            matTo(pre.Rt, m12, 12); gRt1.insert(gRt1.end(), m12, m12 + 12);
+            matTo(cur.Rt, m12, 12); gRt2.insert(gRt2.end(), m12, m12 + 12);
+            matTo(pre.K, k9, 9); gK1.insert(gK1.end(), k9, k9 + 9);
+            matTo(cur.K, k9, 9); gK2.insert(gK2.end(), k9, k9 + 9);
+            ofs.push_back(ofs.back() + (int32_t)pairs.size());
+            gstream.push_back(b);
+            gpairs.push_back(std::move(pairs));
+        }
+        const int G = (int)gstream.size();
+        if (G == 0) continue;
+        std::vector<double> gX((size_t)ofs.back() * 3);
+        chk(mslam_triangulate_batch(runner_->ctx(), gx1.data(), gx2.data(), ofs.data(), G, gRt1.data(), gRt2.data(), gK1.data(), gK2.data(), gX.data(), nullptr, nullptr),
+            "mslam_triangulate_batch");
+        for (int g = 0; g < G; g++) {
+            DataManager& data = *dms_[(size_t)gstream[(size_t)g]];
+            const double* Xn = gX.data() + (size_t)ofs[(size_t)g] * 3;
+            for (size_t k = 0; k < gpairs[(size_t)g].size(); k++)
+                registerNewMapPoint(data, Point3d(Xn[3 * k], Xn[3 * k + 1], Xn[3 * k + 2]), data.frames[(size_t)i], gpairs[(size_t)g][k].first,
+                                    data.frames[(size_t)frameIdx], gpairs[(size_t)g][k].second);
         }
     }
 }

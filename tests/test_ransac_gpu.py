@@ -160,6 +160,30 @@ def test_triangulate_matches_oracle(ctx, oracle):
     assert ng2 == no2 and ng2 < 300
 
 
+def test_triangulate_batch_equals_single_calls(ctx):
+    """mslam_triangulate_batch: ragged groups (one empty) with their own cameras -- point for point the bits of mslam_triangulate."""
+    tvs = [synth.two_view_problem(n, 30 + i, outlier_frac=0.0) for i, n in enumerate((130, 1, 77, 300))]
+    ofs = [0]
+    x1, x2, Rt1, Rt2, K1, K2 = [], [], [], [], [], []
+    sizes = [130, 1, 0, 77, 300]
+    src = [tvs[0], tvs[1], tvs[1], tvs[2], tvs[3]]
+    for n, tv in zip(sizes, src):
+        x1.append(tv["x1"][:n]); x2.append(tv["x2"][:n])
+        Rt1.append(np.eye(3, 4)); Rt2.append(np.concatenate([tv["R"], (tv["t"] if n != 77 else -tv["t"])[:, None]], axis=1))
+        K1.append(tv["K"]); K2.append(tv["K"])
+        ofs.append(ofs[-1] + n)
+    X, front, nf = ctx.triangulate_batch(np.concatenate(x1), np.concatenate(x2), ofs, np.stack(Rt1), np.stack(Rt2), np.stack(K1), np.stack(K2))
+    for g, n in enumerate(sizes):
+        if n == 0:
+            assert nf[g] == 0
+            continue
+        Xs, fs, ns = ctx.triangulate(x1[g], x2[g], Rt1[g], Rt2[g], K1[g], K2[g])
+        np.testing.assert_array_equal(X[ofs[g]:ofs[g + 1]], Xs)
+        np.testing.assert_array_equal(front[ofs[g]:ofs[g + 1]], fs)
+        assert nf[g] == ns
+    assert nf[3] < 77 and nf[4] == 300
+
+
 def test_pnp_threshold_shell_and_camera_plane(ctx, oracle):
     """The division-free inlier test must hand every undecided point to the exact rule: observations placed at
     thr * (1 +- tiny) from the noise-free projection, world points on (and next to) the camera plane z = 0."""
