@@ -146,12 +146,12 @@ void resize_k(const uint8_t* __restrict__ src, int spitch, long long sfstride,
 #pragma unroll
             for (int k = 0; k < RS_HROWS / 2; k++) {
                 const int r = 2 * k + rh;
-                v[k] = (c_ok && r < nrows) ? sb32[(unsigned)((sy_lo + r) * spitch_dw) + col] : 0u;
+                v[k] = (c_ok && r < nrows) ? sb32[__umul24((unsigned)(sy_lo + r), (unsigned)spitch_dw) + col] : 0u; // 24-bit multiplies: full rate (v_mul_lo_u32 is quarter rate)
             }
 #pragma unroll
             for (int k = 0; k < RS_HROWS / 2; k++) {
                 const int r = 2 * k + rh;
-                if (c_ok && r < nrows) s_src[r * ndw + c] = v[k];
+                if (c_ok && r < nrows) s_src[__umul24((unsigned)r, (unsigned)ndw) + c] = v[k];
             }
         }
         __syncthreads();
@@ -183,14 +183,14 @@ void resize_k(const uint8_t* __restrict__ src, int spitch, long long sfstride,
             uint32_t out = 0;
 #pragma unroll
             for (int i = 0; i < 4; i++) { // v <= 255: no masking needed
-                const uint32_t A = (uint32_t)yt.z * ha[i], Bv = (uint32_t)yt.w * hb[i];
+                const uint32_t A = __umul24((uint32_t)yt.z, ha[i]), Bv = __umul24((uint32_t)yt.w, hb[i]); // <= 2048 x 32640
                 // (A >> 16) + (Bv >> 16) + 2: high halves gathered by one v_perm, summed by v_dot2_u32_u16 with weights (1, 1)
                 typedef unsigned short us2 __attribute__((ext_vector_type(2)));
                 const uint32_t hh = __builtin_amdgcn_perm(Bv, A, 0x07060302u);
                 const uint32_t v = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, hh), (us2){1, 1}, 2u, false) >> 2;
                 out |= v << (8 * i);
             }
-            *reinterpret_cast<uint32_t*>(db + (size_t)y * dpitch + x4) = out;
+            *reinterpret_cast<uint32_t*>(db + (__umul24((unsigned)y, (unsigned)dpitch) + (unsigned)x4)) = out;
         }
         return;
     }
@@ -640,7 +640,7 @@ void describe_k(OrbDev od, DescArgs out)
 #pragma unroll
         for (int k = 0; k < 9; k++) {
             const int r = r0 + 5 * k;
-            v[k] = (active && lane < 60 && r < DP_N) ? img32[(unsigned)((py0 + r) * pitch_dw) + col] : 0u;
+            v[k] = (active && lane < 60 && r < DP_N) ? img32[__umul24((unsigned)(py0 + r), (unsigned)pitch_dw) + col] : 0u;
         }
 #pragma unroll
         for (int k = 0; k < 9; k++) {
@@ -658,8 +658,8 @@ void describe_k(OrbDev od, DescArgs out)
         const uint8_t* row = raw + (DP_R + v) * DP_PITCH + DP_R;
         int rs = 0;
         const int u0 = half ? 1 : -dmax, u1 = half ? dmax : 0;
-        for (int u = u0; u <= u1; u++) { const int val = row[u]; m10 += u * val; rs += val; }
-        m01 = v * rs;
+        for (int u = u0; u <= u1; u++) { const int val = row[u]; m10 += __mul24(u, val); rs += val; }   // v_mad_i32_i24
+        m01 = __mul24(v, rs);
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { m10 += __shfl_xor(m10, o); m01 += __shfl_xor(m01, o); }
@@ -732,8 +732,8 @@ void describe_k(OrbDev od, DescArgs out)
         const int8_t* pt = c_pattern + (j * 64 + lane) * 4;
         float x0 = pt[0] * ca - pt[1] * sb, y0 = pt[0] * sb + pt[1] * ca;
         float x1 = pt[2] * ca - pt[3] * sb, y1 = pt[2] * sb + pt[3] * ca;
-        int t0 = centre[__float2int_rn(x0) * (BT_DW * 4) + __float2int_rn(y0)];
-        int t1 = centre[__float2int_rn(x1) * (BT_DW * 4) + __float2int_rn(y1)];
+        int t0 = centre[__mul24(__float2int_rn(x0), BT_DW * 4) + __float2int_rn(y0)];
+        int t1 = centre[__mul24(__float2int_rn(x1), BT_DW * 4) + __float2int_rn(y1)];
         bits[j] = __ballot(t0 < t1);
     }
     if (!active) return;
