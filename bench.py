@@ -189,18 +189,52 @@ def main():
     if world > 1 or args.force_collective:
         collective = {"what": "all-gather of int32[%d] PnP inlier counts per rank per frame-step" % PNP_H, "ranks": world,
                       "bytes": 4 * PNP_H * world, "per_step": T}
-        try:
-            uid = api.Comm.unique_id() if rank == 0 else bytes(128)
-            if world > 1:
-                import torch
-                t = torch.tensor(list(uid), dtype=torch.uint8)
-                dist.broadcast(t, src=0)
-                uid = bytes(t.tolist())
-            comm = api.Comm(tbs[0].pnp_ctx, uid, rank, world)
-            tbs[0].set_comm(comm)
-            collective.update(backend="rccl (mslam_comm_allgather_i32_dev, on the PnP stream)", library=rccl_path, **comm.info())
-        except api.MslamError as e:   # e.g. several rehearsal ranks on one device: RCCL refuses duplicate GPUs
-            collective.update(backend="gloo (host, once per step) -- RCCL communicator unavailable", library=rccl_path, error=str(e)[:300])
+        # Every rank takes the same decision: the id is broadcast unconditionally, the communicator is created and tried once
+        # (a 4-int all-gather) under a watchdog, and the ranks agree over gloo on whether ALL of them succeeded -- a rank that
+        # cannot initialise RCCL must not leave the others blocked inside a collective.
+        import threading
+        uid, uid_err = bytes(128), None
+        if rank == 0:
+            try:
+                uid = api.Comm.unique_id()
+            except api.MslamError as e:
+                uid_err = str(e)
+        if world > 1:
+            import torch
+            t = torch.tensor(list(uid), dtype=torch.uint8)
+            dist.broadcast(t, src=0)
+            uid = bytes(t.tolist())
+        box = {}
+
+        def make_comm():
+            try:
+                c = api.Comm(tbs[0].pnp_ctx, uid, rank, world)
+                probe = c.allgather_i32(np.arange(4, dtype=np.int32) + 10 * rank)
+                assert (probe.reshape(world, 4) == np.arange(4)[None, :] + 10 * np.arange(world)[:, None]).all(), "all-gather probe mismatch"
+                box["comm"] = c
+            except Exception as e:   # MslamError (RCCL refused / unavailable) or a failed probe
+                box["err"] = str(e)[:300]
+        if any(uid):
+            th = threading.Thread(target=make_comm, daemon=True)
+            th.start()
+            th.join(float(os.environ.get("BENCH_COMM_TIMEOUT", "120")))
+            if th.is_alive():
+                box["err"] = "RCCL communicator creation did not return within the watchdog time"
+                collective["watchdog_fired"] = True
+        else:
+            box["err"] = uid_err or "no RCCL unique id"
+        all_ok = "comm" in box
+        if world > 1:
+            import torch
+            t = torch.tensor([1 if all_ok else 0], dtype=torch.int32)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            all_ok = bool(t.item())
+        if all_ok:
+            tbs[0].set_comm(box["comm"])
+            collective.update(backend="rccl (mslam_comm_allgather_i32_dev, on the PnP stream)", library=rccl_path, **box["comm"].info())
+        else:   # e.g. several rehearsal ranks on one device: RCCL refuses duplicate GPUs
+            collective.update(backend="gloo (host, once per step) -- RCCL communicator unavailable on at least one rank", library=rccl_path,
+                              error=box.get("err", "another rank failed"))
 
     def gloo_gather_fallback():
         if collective is not None and tbs[0].comm is None and world > 1:
@@ -369,6 +403,9 @@ def main():
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+    if collective is not None and collective.get("watchdog_fired"):
+        sys.stdout.flush()
+        os._exit(0)   # a thread is stuck inside RCCL: do not wait for it in the interpreter's teardown
 
 
 def roofline_blocks(kern, kern_x, nprof, SB, NS, value, world) -> dict:
