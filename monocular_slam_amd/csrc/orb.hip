@@ -323,7 +323,6 @@ void fast_nms_k(OrbDev od)
     // pixels contains pixel 0 or 8 AND pixel 4 or 12 of that polarity.  All predicates are wavefront lane masks
     // (v_cmp -> SGPR pair, logic on the scalar unit); the survivors are appended to s_list by ballot compaction.
     const int lane = tid & 63;
-    const unsigned long long below = (1ull << lane) - 1ull;
     {
         const int g = tid & 31, ry = tid >> 5;
         unsigned long long colok[4]; // lanes whose pixel 4g + k lies inside the needed score columns
@@ -358,7 +357,9 @@ void fast_nms_k(OrbDev od)
                 base = __shfl(base, 0);
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
-                    if (__builtin_amdgcn_inverse_ballot_w64(bal[k])) s_list[base + __popcll(bal[k] & below)] = (uint16_t)(sy * FS_W + 4 * g + k);
+                    // rank of this lane among the survivors of slot k: v_mbcnt_lo/hi take the lane mask straight from SGPRs
+                    const int rank_k = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal[k] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal[k], 0u));
+                    if (__builtin_amdgcn_inverse_ballot_w64(bal[k])) s_list[base + rank_k] = (uint16_t)(sy * FS_W + 4 * g + k);
                     base += __popcll(bal[k]);
                 }
             }
