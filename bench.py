@@ -43,7 +43,7 @@ ALG_BYTES = {
     "pnp": 40 * PNP_P + 4 * 4 * PNP_H + 48 + PNP_P + 4 * PNP_H,
 }
 KERNEL_UNIT = {  # which per-frame unit a kernel's launch is priced against
-    "bgr2gray_k": "extract", "resize_k": "extract", "pyramid_k": "extract", "fast_nms_k": "extract", "select_k": "extract",
+    "bgr2gray_k": "extract", "resize_k": "extract", "pyramid2_k": "extract", "fast_nms_k": "extract", "select_k": "extract",
     "describe_k": "extract", "hamming_knn2_partial": "match", "knn2_finalize": "match",
     "pnp_prepare_k": "pnp", "pnp_solve_k": "pnp", "pnp_score_k": "pnp", "ransac_select_k": "pnp", "pnp_finalize_k": "pnp",
 }

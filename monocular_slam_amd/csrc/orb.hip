@@ -16,7 +16,9 @@
 //   candidate list cannot overflow.
 // Kernels (one launch each per batch unless noted):
 //   bgr2gray_k      BGR[A] -> gray, fixed point (only for 3/4-channel input)
-//   resize_k        level l-1 -> l, 11-bit fixed-point bilinear (L-1 launches: serial dependency)
+//   resize_k        level l-1 -> l, 11-bit fixed-point bilinear (serial dependency between levels)
+//   pyramid2_k      levels l and l+1 from level l-1 in one launch (level l stays in LDS for the second resize); used for
+//                   the pairs (2,3), (4,5), (6,7): 4 pyramid launches instead of 7, levels 2/4/6 are never read back
 //   fast_nms_k      all levels x frames: 64x32 pixel tiles staged in LDS with a 4-px halo;
 //                   3-phase (high-speed reject -> dense survivor list -> exact score) so that
 //                   lanes stay busy; 3x3 NMS on an LDS score tile; wave-aggregated append
@@ -65,6 +67,7 @@ struct LevelDesc {
     int cand_cap; uint32_t* cand; uint32_t* candA; float* respA;
     int nfeat; float sf, inv_sf;
     int2* xtab; int4* ytab;            // resize tables for producing THIS level from l-1
+    int fused_with_next;               // 1: this level and the next one are produced together from level l-1 (pyramid2_k)
 };
 
 struct OrbDev {
@@ -218,6 +221,146 @@ void resize_k(const uint8_t* __restrict__ src, int spitch, long long sfstride,
             out |= (uint32_t)(v & 255) << (8 * i);
         }
         *reinterpret_cast<uint32_t*>(db + (size_t)y * dpitch + x4) = out;
+    }
+}
+
+// Two pyramid levels per launch: level A = l+1 and level B = l+2 from level S = l.  A workgroup owns a 128 x 16 tile of B.
+// It stages the source footprint of the A pixels that tile needs, produces those A pixels in LDS (same two integer passes as
+// resize_k), stores the part of them it OWNS to HBM (A is partitioned over the workgroups by the first A column / row each B
+// tile needs, rounded down to a multiple of 4 columns so that every store is an aligned dword), and produces the B tile
+// from the A pixels in LDS.  Against two resize_k launches: level A is not read back from HBM (1.35 x its area with the tile
+// halos) and one launch is saved; the price is the recomputation of the A pixels two neighbouring tiles share.
+constexpr int P2_BW = 128, P2_BH = 16;           // B tile
+constexpr int P2_AW = 176, P2_AH = 24;           // A region bound (columns multiple of 4, rows)
+constexpr int P2_SDW = 56, P2_SH = 32;           // source footprint bound: dwords per row, rows
+struct Pyr2Args {
+    const uint8_t* S; int spitch; long long sfstride;
+    uint8_t* A; int wA, hA, apitch; long long afstride; const int2* xtA; const int4* ytA;
+    uint8_t* Bm; int wB, hB, bpitch; long long bfstride; const int2* xtB; const int4* ytB;
+};
+__global__ __launch_bounds__(256)
+void pyramid2_k(Pyr2Args a)
+{
+    // (+ 8 dwords each: the 4-column groups at the right edge of a region read a few bytes past it; those columns are discarded)
+    __shared__ uint32_t s_src[P2_SH * P2_SDW + 8];        // source footprint (bytes)
+    __shared__ uint16_t s_h[P2_SH * P2_AW];               // horizontal sums >> 4: first for A (source rows), then for B (A rows)
+    __shared__ uint32_t s_A[P2_AH * P2_AW / 4 + 8];       // A region (bytes), pitch P2_AW
+    const int tid = threadIdx.x, b = blockIdx.z;
+    const int xB0 = blockIdx.x * P2_BW, yB0 = blockIdx.y * P2_BH;
+    const int xB1 = min(xB0 + P2_BW, a.wB) - 1, yB1 = min(yB0 + P2_BH, a.hB) - 1;
+    const bool lastx = xB0 + P2_BW >= a.wB, lasty = yB0 + P2_BH >= a.hB;
+    // A region: owned = [ox0, ox1) x [oy0, oy1), computed = [ox0, cx1] x [oy0, cy1]
+    const int ox0 = blockIdx.x == 0 ? 0 : ((a.xtB[xB0].x & 0xFFFF) & ~3);
+    const int ox1 = lastx ? ((a.wA + 3) & ~3) : ((a.xtB[xB0 + P2_BW].x & 0xFFFF) & ~3);
+    const int cx1 = lastx ? a.wA - 1 : (int)((unsigned)a.xtB[xB1].x >> 16);
+    const int oy0 = blockIdx.y == 0 ? 0 : a.ytB[yB0].x;
+    const int oy1 = lasty ? a.hA : a.ytB[yB0 + P2_BH].x;
+    const int cy1 = lasty ? a.hA - 1 : a.ytB[yB1].y;
+    const int caw = cx1 - ox0 + 1, cah = cy1 - oy0 + 1;   // <= P2_AW, P2_AH (checked on the host against the tables)
+    // source footprint of the A region
+    const int sx_lo = a.xtA[ox0].x & 0xFFFF, sx_hi = (int)((unsigned)a.xtA[cx1].x >> 16);
+    const int sy_lo = a.ytA[oy0].x, sy_hi = a.ytA[cy1].y;
+    const int sxa = sx_lo & ~3;
+    const int ndw = ((sx_hi - sxa) >> 2) + 1, nrows = sy_hi - sy_lo + 1;   // <= P2_SDW, P2_SH
+    {
+        const uint32_t* sb32 = reinterpret_cast<const uint32_t*>(a.S + b * a.sfstride);
+        const int max_dw = a.spitch / 4 - 1, spitch_dw = a.spitch / 4;
+        for (int i = tid; i < nrows * P2_SDW; i += 256) {
+            const int r = i / P2_SDW, c = i - r * P2_SDW;
+            if (c < ndw) s_src[r * P2_SDW + c] = sb32[__umul24((unsigned)(sy_lo + r), (unsigned)spitch_dw) + (unsigned)min(sxa / 4 + c, max_dw)];
+        }
+    }
+    __syncthreads();
+    // ---- A, horizontal: thread = (column group of 4, row lane); 44 groups x 5 row lanes
+    {
+        const int g = tid % 44, rl = tid / 44;
+        if (rl < 5 && 4 * g < caw) {
+            int o0[4], a0[4], a1[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int2 t = a.xtA[min(ox0 + 4 * g + i, a.wA - 1)];
+                o0[i] = (t.x & 0xFFFF) - sxa; a0[i] = t.y & 0xFFFF; a1[i] = (int)((unsigned)t.y >> 16);
+            }
+            const uint8_t* lds = reinterpret_cast<const uint8_t*>(s_src);
+            for (int r = rl; r < nrows; r += 5) {
+                const uint8_t* row = lds + r * (P2_SDW * 4);
+                uint32_t h[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) h[i] = (uint32_t)(__umul24(row[o0[i]], a0[i]) + __umul24(row[o0[i] + 1], a1[i])) >> 4;
+                *reinterpret_cast<uint2*>(&s_h[r * P2_AW + 4 * g]) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+            }
+        }
+    }
+    __syncthreads();
+    // ---- A, vertical: into LDS, and the owned part to HBM
+    {
+        const int g = tid % 44, rl = tid / 44;
+        if (rl < 5 && 4 * g < caw) {
+            uint8_t* ab = a.A + b * a.afstride;
+            for (int r = rl; r < cah; r += 5) {
+                const int y = oy0 + r;
+                const int4 yt = a.ytA[y];
+                const uint16_t* ha = s_h + (yt.x - sy_lo) * P2_AW + 4 * g;
+                const uint16_t* hb = s_h + (yt.y - sy_lo) * P2_AW + 4 * g;
+                uint32_t out = 0;
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const uint32_t Av = __umul24((uint32_t)yt.z, ha[i]), Bv = __umul24((uint32_t)yt.w, hb[i]);
+                    typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+                    const uint32_t hh = __builtin_amdgcn_perm(Bv, Av, 0x07060302u);
+                    const uint32_t v = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, hh), (us2){1, 1}, 2u, false) >> 2;
+                    out |= v << (8 * i);
+                }
+                s_A[r * (P2_AW / 4) + g] = out;
+                const int x = ox0 + 4 * g;
+                if (x < ox1 && y < oy1) *reinterpret_cast<uint32_t*>(ab + (__umul24((unsigned)y, (unsigned)a.apitch) + (unsigned)x)) = out;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- B, horizontal from the A region in LDS: thread = (column group of 4, row lane); 32 groups x 8 row lanes
+    {
+        const int g = tid & 31, rl = tid >> 5;
+        if (xB0 + 4 * g <= xB1) {
+            int o0[4], a0[4], a1[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int2 t = a.xtB[min(xB0 + 4 * g + i, a.wB - 1)];
+                o0[i] = (t.x & 0xFFFF) - ox0; a0[i] = t.y & 0xFFFF; a1[i] = (int)((unsigned)t.y >> 16);
+            }
+            const uint8_t* lds = reinterpret_cast<const uint8_t*>(s_A);
+            for (int r = rl; r < cah; r += 8) {
+                const uint8_t* row = lds + r * P2_AW;
+                uint32_t h[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) h[i] = (uint32_t)(__umul24(row[o0[i]], a0[i]) + __umul24(row[o0[i] + 1], a1[i])) >> 4;
+                *reinterpret_cast<uint2*>(&s_h[r * P2_AW + 4 * g]) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+            }
+        }
+    }
+    __syncthreads();
+    // ---- B, vertical: 16 rows x 32 groups, two rows per thread
+    {
+        const int g = tid & 31, rl = tid >> 5;
+        uint8_t* bb = a.Bm + b * a.bfstride;
+        if (xB0 + 4 * g <= xB1)
+            for (int r = rl; r < P2_BH; r += 8) {
+                const int y = yB0 + r;
+                if (y > yB1) break;
+                const int4 yt = a.ytB[y];
+                const uint16_t* ha = s_h + (yt.x - oy0) * P2_AW + 4 * g;
+                const uint16_t* hb = s_h + (yt.y - oy0) * P2_AW + 4 * g;
+                uint32_t out = 0;
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const uint32_t Av = __umul24((uint32_t)yt.z, ha[i]), Bv = __umul24((uint32_t)yt.w, hb[i]);
+                    typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+                    const uint32_t hh = __builtin_amdgcn_perm(Bv, Av, 0x07060302u);
+                    const uint32_t v = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, hh), (us2){1, 1}, 2u, false) >> 2;
+                    out |= v << (8 * i);
+                }
+                *reinterpret_cast<uint32_t*>(bb + (__umul24((unsigned)y, (unsigned)a.bpitch) + (unsigned)(xB0 + 4 * g))) = out;
+            }
     }
 }
 
@@ -896,8 +1039,11 @@ static int orb_plan_get(mslam_ctx* ctx, int w, int h, int B, int channels, const
     od.frame_status = od.sel_cnt + n_cnt;
     od.sel = (uint2*)(base + off_sel);
     std::vector<int4> tab;
+    std::vector<std::vector<int2>> h_xt((size_t)L);
+    std::vector<std::vector<int4>> h_yt((size_t)L);
     for (int l = 0; l < L; l++) {
         LevelDesc& lv = od.lv[l];
+        lv.fused_with_next = 0;
         lv.img = (uint8_t*)(base + off_img[l]);
         lv.cand = (uint32_t*)(base + off_cand[l]);
         lv.candA = (uint32_t*)(base + off_candA[l]);
@@ -921,6 +1067,7 @@ static int orb_plan_get(mslam_ctx* ctx, int w, int h, int B, int channels, const
             xt[(size_t)dx] = make_int2(sx | (sx1 << 16), (a0 & 0xFFFF) | (a1 << 16)); // 0 <= a0, a1 <= 2048
         }
         HIP_TRY(ctx, hipMemcpy(lv.xtab, xt.data(), sizeof(int2) * (size_t)dw, hipMemcpyHostToDevice));
+        h_xt[(size_t)l] = xt;
         tab.assign((size_t)dh, make_int4(0, 0, 0, 0));
         for (int dy = 0; dy < dh; dy++) {
             float fy = (float)((dy + 0.5) * scale_y - 0.5);
@@ -932,6 +1079,40 @@ static int orb_plan_get(mslam_ctx* ctx, int w, int h, int B, int channels, const
                                 sat_short_host(cv_round_host(fy * 2048)));
         }
         HIP_TRY(ctx, hipMemcpy(lv.ytab, tab.data(), sizeof(int4) * (size_t)dh, hipMemcpyHostToDevice));
+        h_yt[(size_t)l] = tab;
+    }
+    // Which level pairs (A = l, B = l + 1) can be produced together from level l - 1: every 128 x 16 tile of B must keep its
+    // A region and that region's source footprint inside pyramid2_k's LDS bounds (true for scale factors up to ~1.25)
+    // Level 1 (69 % of the pyramid's pixels together with level 2) stays a resize_k launch: fusing the pair (1, 2) costs 7 % more
+    // time than two launches (the shared A pixels are recomputed), while the pairs (2, 3), (4, 5), (6, 7) are faster fused
+    // (measured per 32 frames, tools/sweep_pyramid_fusion.sh: none 0.186 ms, from level 1: 0.194, from level 2: 0.180).
+    // MSLAM_PYRAMID_FUSE (development): first level of the first fused pair (0 = no fusion).
+    const int fuse_first = getenv("MSLAM_PYRAMID_FUSE") ? atoi(getenv("MSLAM_PYRAMID_FUSE")) : 2;
+    for (int l = fuse_first; fuse_first >= 1 && l + 1 < L; l += 2) {
+        const LevelDesc& A = od.lv[l];
+        const LevelDesc& Bv = od.lv[l + 1];
+        const std::vector<int2>& xtA = h_xt[(size_t)l]; const std::vector<int4>& ytA = h_yt[(size_t)l];
+        const std::vector<int2>& xtB = h_xt[(size_t)l + 1]; const std::vector<int4>& ytB = h_yt[(size_t)l + 1];
+        bool ok = true;
+        for (int xB0 = 0; xB0 < Bv.w && ok; xB0 += P2_BW) {
+            const int xB1 = std::min(xB0 + P2_BW, Bv.w) - 1;
+            const bool lastx = xB0 + P2_BW >= Bv.w;
+            const int ox0 = xB0 == 0 ? 0 : ((xtB[(size_t)xB0].x & 0xFFFF) & ~3);
+            const int cx1 = lastx ? A.w - 1 : (int)((unsigned)xtB[(size_t)xB1].x >> 16);
+            const int needed_lo = xtB[(size_t)xB0].x & 0xFFFF;
+            if (cx1 - ox0 + 1 > P2_AW || cx1 < ox0 || ox0 > needed_lo) { ok = false; break; }
+            const int sx_lo = xtA[(size_t)ox0].x & 0xFFFF, sx_hi = (int)((unsigned)xtA[(size_t)cx1].x >> 16);
+            if (((sx_hi - (sx_lo & ~3)) >> 2) + 1 > P2_SDW) ok = false;
+        }
+        for (int yB0 = 0; yB0 < Bv.h && ok; yB0 += P2_BH) {
+            const int yB1 = std::min(yB0 + P2_BH, Bv.h) - 1;
+            const bool lasty = yB0 + P2_BH >= Bv.h;
+            const int oy0 = yB0 == 0 ? 0 : ytB[(size_t)yB0].x;
+            const int cy1 = lasty ? A.h - 1 : ytB[(size_t)yB1].y;
+            if (cy1 - oy0 + 1 > P2_AH || cy1 < oy0 || oy0 > ytB[(size_t)yB0].x) { ok = false; break; }
+            if (ytA[(size_t)cy1].y - ytA[(size_t)oy0].x + 1 > P2_SH) ok = false;
+        }
+        od.lv[l].fused_with_next = ok ? 1 : 0;
     }
     pl->level0 = od.lv[0].img;
     pl->level0_pitch = od.lv[0].pitch;
@@ -986,6 +1167,14 @@ int mslam_orb_extract_batch_dev(mslam_ctx* ctx, const uint8_t* imgs, int B, int 
     for (int l = 1; l < od.L; l++) {
         const LevelDesc& s = od.lv[l - 1];
         const LevelDesc& d = od.lv[l];
+        if (d.fused_with_next) {   // levels l and l + 1 from level l - 1 in one launch
+            const LevelDesc& e = od.lv[l + 1];
+            Pyr2Args pa{ s.img, s.pitch, s.frame_stride, d.img, d.w, d.h, d.pitch, d.frame_stride, d.xtab, d.ytab,
+                         e.img, e.w, e.h, e.pitch, e.frame_stride, e.xtab, e.ytab };
+            LAUNCH(ctx, K_PYRAMID2, pyramid2_k, dim3((e.w + P2_BW - 1) / P2_BW, (e.h + P2_BH - 1) / P2_BH, B), dim3(256), 0, pa);
+            l++;
+            continue;
+        }
         LAUNCH(ctx, K_RESIZE, resize_k, dim3((d.w + RS_TW - 1) / RS_TW, (d.h + RS_TH - 1) / RS_TH, B), dim3(256), 0, s.img, s.pitch, s.frame_stride,
                            d.img, d.w, d.h, d.pitch, d.frame_stride, d.xtab, d.ytab);
     }
