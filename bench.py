@@ -320,6 +320,10 @@ def main():
     kern, kern_x = {}, {}
     NPROF = 8  # frame-steps per instrumented pass
     if not args.no_kernel_events and rank == 0:
+        # only rank 0 runs these passes: the collective must stay out of them (the other ranks are not there to answer it)
+        saved_comm = tbs[0].comm
+        tbs[0].comm = None
+
         def read(into):
             for c in ctxs:
                 for k, (ms, n) in c.profile_read().items():
@@ -340,6 +344,7 @@ def main():
                 tb.pnp_ransac(); tb.sync()
                 tb.advance()
         read(kern_x)
+        tbs[0].comm = saved_comm
 
     # ---- separately timed leg: the same steps with every frame set uploaded from pinned host memory on a copy stream
     # (double-buffered against the previous step's kernels).  PCIe-inclusive; reported beside `value`, never as it.
