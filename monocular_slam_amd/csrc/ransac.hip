@@ -913,7 +913,7 @@ __device__ int p3p(const double* f, const double* X, double (*Rout)[9], double (
     return nsol;
 }
 
-__global__ __launch_bounds__(64)
+__global__ __launch_bounds__(64, 2)   // <= 256 VGPRs: two wavefronts per SIMD cover each other's f64 divide / sqrt chains (288 VGPRs = one)
 void pnp_solve_k(PnpArgs a)
 {
     const int b = blockIdx.y;
