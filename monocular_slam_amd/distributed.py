@@ -22,9 +22,19 @@ def stream_ids(streams_per_rank: int, rank: int) -> range:
     return range(rank * streams_per_rank, (rank + 1) * streams_per_rank)
 
 
-def allgather_counts(local_counts: np.ndarray, total: int, dist=None, device=None) -> np.ndarray:
-    """All-gather ragged int32 slices (shard_range order) into the full per-hypothesis count vector."""
+def allgather_counts(local_counts: np.ndarray, total: int, dist=None, device=None, comm=None) -> np.ndarray:
+    """All-gather ragged int32 slices (shard_range order) into the full per-hypothesis count vector.
+
+    comm: an api.Comm (mslam_comm_*: RCCL at the C ABI, one rank per GPU) -- the native path; otherwise a torch.distributed
+    process group (gloo in the CPU tests)."""
     local_counts = np.ascontiguousarray(local_counts, np.int32)
+    if comm is not None:
+        world = comm.nranks
+        width = -(-total // world)  # pad every slice to the same length: one fixed-size collective
+        buf = np.full(width, -1, np.int32)
+        buf[: local_counts.shape[0]] = local_counts
+        out = comm.allgather_i32(buf).reshape(world, width)
+        return np.concatenate([out[r, : shard_range(total, r, world)[1] - shard_range(total, r, world)[0]] for r in range(world)])
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
         assert local_counts.shape[0] == total
         return local_counts
@@ -59,7 +69,7 @@ def max_over_ranks(value: float, dist=None, device=None) -> float:
     return float(t.item())
 
 
-def sharded_pnp_ransac(ctx, X, x, K, dist_coeffs, samples, params, dist=None, device=None, rank=None, world=None):
+def sharded_pnp_ransac(ctx, X, x, K, dist_coeffs, samples, params, dist=None, device=None, rank=None, world=None, comm=None):
     """ONE PnP RANSAC problem with its hypotheses sharded over ranks (BASELINE config C4).
 
     Every rank scores its contiguous slice of the sample table on its own GPU (`ctx.pnp_ransac`); with a process group the
@@ -72,6 +82,10 @@ def sharded_pnp_ransac(ctx, X, x, K, dist_coeffs, samples, params, dist=None, de
     assert params.confidence == 0.0, "sharded scoring uses the plain argmax rule"
     samples = np.ascontiguousarray(samples, np.int32)
     H = samples.shape[0]
+    if comm is not None:   # native RCCL communicator: rank / size come from it
+        lo, hi = shard_range(H, comm.rank, comm.nranks)
+        local = ctx.pnp_ransac(X, x, K, dist_coeffs, samples[lo:hi], params)["counts"] if hi > lo else np.zeros(0, np.int32)
+        return lo, hi, local, allgather_counts(local, H, comm=comm)
     grouped = dist is not None and dist.is_initialized() and dist.get_world_size() > 1 and rank is None
     if grouped:
         rank, world = dist.get_rank(), dist.get_world_size()

@@ -55,3 +55,22 @@ def test_single_process_allgather_one_device(ctx):
     # invalid: the same device twice
     with pytest.raises(api.MslamError):
         api.allgather_i32_single_process([ctx, ctx], np.zeros((2, 4), np.int32))
+
+
+def test_sharded_pnp_over_the_native_communicator(ctx, oracle):
+    """distributed.sharded_pnp_ransac with an api.Comm (world size 1 here): slice scoring, RCCL all-gather of the padded count
+    slices, global winner and its refinement equal the unsharded call."""
+    from monocular_slam_amd import api, synth, distributed as D
+    pr = synth.pnp_problem(400, 17)
+    S = synth.sample_table(400, 301, 4, 3)
+    pp = api.default_pnp_params(); pp.reproj_thr = 2.0
+    comm = api.Comm(ctx, api.Comm.unique_id(), 0, 1)
+    try:
+        lo, hi, local, full = D.sharded_pnp_ransac(ctx, pr["X"], pr["x"], pr["K"], pr["dist"], S, pp, comm=comm)
+        assert (lo, hi) == (0, 301) and (full == local).all()
+        out = D.finish_sharded_pnp(ctx, pr["X"], pr["x"], pr["K"], pr["dist"], S, pp, full)
+        ref = ctx.pnp_ransac(pr["X"], pr["x"], pr["K"], pr["dist"], S, pp)
+        assert out["best_h"] == ref["best_h"] and (full == ref["counts"]).all()
+        np.testing.assert_array_equal(out["Rt"], ref["Rt"])
+    finally:
+        comm.close()
