@@ -248,6 +248,23 @@ int mslam_triangulate(mslam_ctx* ctx, const double* x1, const double* x2, int n,
                       const double Rt1[12], const double Rt2[12], const double K1[9], const double K2[9],
                       double* X, uint8_t* front, int* n_front);
 
+/* ---- device-side preparation of batched RANSAC inputs (what the stage classes otherwise assemble on the host) ----------
+ * RANSAC in the reference draws its samples inside OpenCV (cv::findFundamentalMat / cv::solvePnPRansac,
+ * src/CameraPoseEstimator.cpp:585, :472); here the sample tables are explicit inputs, and this is the stated generator
+ * the stages use for them (monocular_slam_amd/host/Geometry.h geom::sampleTable, restated in tests/ref_pipeline.py):
+ * table b = H rows of k distinct indices in [0, n[b]); row h is drawn by xorshift64* started from
+ * splitmix64(seeds[b] + (h + 1) * 0x9E3779B97F4A7C15) (a zero state is replaced by that constant), each index
+ * (next() >> 32) % n[b], repeats within the row redrawn.  Rows are independent, so one thread draws one row.
+ * n, seeds: device arrays of B; tables: device, B x H x k.  n[b] < k gives a zero table.  1 <= k <= 8. */
+int mslam_sample_tables_dev(mslam_ctx* ctx, const int32_t* n, const uint64_t* seeds, int H, int k, int B, int32_t* tables);
+/* Matched pixel coordinates for mslam_fmat_ransac8_batch_dev from device-resident keypoints and match lists
+ * (the gather of computeFundamentalMatrix, src/CameraPoseEstimator.cpp:553-571): for i < count[b]
+ *   x1[b][i] = (double) kps_q[b][query[b][i]].(x, y),   x2[b][i] = (double) kps_t[b][train[b][i]].(x, y)
+ * (float -> double widening, as Point2f -> Point2d in the reference); kps_*: B x cap keypoints, query/train: B x cap,
+ * x1/x2: B x cap x 2.  M_out[b] = count[b] if count[b] >= min_count else 0 (a problem the RANSAC kernels skip). */
+int mslam_gather_matches_dev(mslam_ctx* ctx, const mslam_keypoint* kps_q, const mslam_keypoint* kps_t, int cap, const int32_t* query,
+                             const int32_t* train, const int32_t* count, int B, int min_count, double* x1, double* x2, int32_t* M_out);
+
 /* G independent groups in one launch sequence (host pointers, synchronous): group g holds points [ofs[g], ofs[g+1]) of
  * x1/x2/X/front (ofs[0] = 0) and its own cameras Rt1/Rt2 (G x 12), K1/K2 (G x 9); n_front: G counts (optional).  Point for
  * point the same arithmetic as mslam_triangulate.  What the batched stages use for the four-candidate cheirality vote

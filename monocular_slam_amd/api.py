@@ -427,6 +427,29 @@ def _ctx_methods():
                     "mslam_triangulate_batch")
         return X, front[:N], nf
 
+    def sample_tables_dev(self, n_ptr, seeds_ptr, H, k, B, tables_ptr):
+        """mslam_sample_tables_dev: B tables of H x k distinct indices, one row per thread (device pointers)."""
+        self._check(lib().mslam_sample_tables_dev(self._h, vp(n_ptr), vp(seeds_ptr), int(H), int(k), int(B), vp(tables_ptr)),
+                    "mslam_sample_tables_dev")
+
+    def sample_tables(self, n, seeds, H, k):
+        """Array form of sample_tables_dev: n (B,) int32, seeds (B,) uint64 -> (B, H, k) int32."""
+        n = np.ascontiguousarray(n, np.int32); seeds = np.ascontiguousarray(seeds, np.uint64)
+        B = n.size
+        dn, ds = DevBuf.from_array(self, n), DevBuf.from_array(self, seeds)
+        dt = DevBuf(self, 4 * B * H * k)
+        self.sample_tables_dev(dn.ptr, ds.ptr, H, k, B, dt.ptr)
+        out = dt.download(np.int32, (B, H, k))
+        for d in (dn, ds, dt):
+            d.free()
+        return out
+
+    def gather_matches_dev(self, kq_ptr, kt_ptr, cap, query_ptr, train_ptr, count_ptr, B, min_count, x1_ptr, x2_ptr, M_ptr):
+        """mslam_gather_matches_dev: matched pixel coordinates (doubles) from resident keypoints + match lists."""
+        self._check(lib().mslam_gather_matches_dev(self._h, vp(kq_ptr), vp(kt_ptr), int(cap), vp(query_ptr), vp(train_ptr), vp(count_ptr),
+                                                   int(B), int(min_count), vp(x1_ptr), vp(x2_ptr), vp(M_ptr) if M_ptr else None),
+                    "mslam_gather_matches_dev")
+
     def fmat_ransac8_batch_dev(self, x1_ptr, x2_ptr, M_ptr, capM, samples_ptr, H, B, params, F_ptr, status_ptr,
                                counts_ptr, best_ptr, ninl_ptr):
         self._check(lib().mslam_fmat_ransac8_batch_dev(self._h, vp(x1_ptr), vp(x2_ptr), vp(M_ptr), capM, vp(samples_ptr), H, B,
@@ -454,7 +477,8 @@ def _ctx_methods():
         a.update(robust_chi2=ss.robust_chi2, n_free_poses=ss.n_free_poses, nnzb=ss.nnzb)
         return a
 
-    for f in (fmat_ransac8, pnp_ransac, triangulate, triangulate_batch, fmat_ransac8_batch_dev, pnp_ransac_batch_dev, ba_build):
+    for f in (fmat_ransac8, pnp_ransac, triangulate, triangulate_batch, sample_tables_dev, sample_tables, gather_matches_dev,
+              fmat_ransac8_batch_dev, pnp_ransac_batch_dev, ba_build):
         setattr(Context, f.__name__, f)
 
 

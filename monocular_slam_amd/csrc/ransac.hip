@@ -1339,6 +1339,60 @@ double sqrt_cut(double thr)
 
 } // namespace
 
+// ---- device-side preparation of batched RANSAC inputs ---------------------------------------------------------------
+__device__ __forceinline__ uint64_t splitmix64(uint64_t z)
+{
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+__global__ __launch_bounds__(256)
+void sample_tables_k(const int32_t* n, const uint64_t* seeds, int H, int k, int32_t* tables)
+{
+    const int b = blockIdx.y, h = blockIdx.x * 256 + threadIdx.x;
+    if (h >= H) return;
+    int32_t* row = tables + ((size_t)b * H + h) * k;
+    const int nb = n[b];
+    if (nb < k) { for (int i = 0; i < k; i++) row[i] = 0; return; }
+    uint64_t s = splitmix64(seeds[b] + (uint64_t)(h + 1) * 0x9E3779B97F4A7C15ull);
+    if (!s) s = 0x9E3779B97F4A7C15ull;
+    int32_t v[8];
+    for (int i = 0; i < k; i++) {
+        bool dup;
+        int32_t c;
+        do { // rejection: k << n
+            s ^= s >> 12; s ^= s << 25; s ^= s >> 27;
+            c = (int32_t)((uint32_t)((s * 0x2545F4914F6CDD1Dull) >> 32) % (uint32_t)nb);
+            dup = false;
+#pragma unroll
+            for (int j = 0; j < 8; j++) dup |= (j < i) & (v[j] == c);
+        } while (dup);
+#pragma unroll
+        for (int j = 0; j < 8; j++) if (j == i) v[j] = c;
+        row[i] = c;
+    }
+}
+
+__global__ __launch_bounds__(256)
+void gather_matches_k(const mslam_keypoint* kq, const mslam_keypoint* kt, int cap, const int32_t* query, const int32_t* train,
+                      const int32_t* count, int min_count, double* x1, double* x2, int32_t* M_out)
+{
+    const int b = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    const int m = count[b];
+    if (i == 0 && M_out) M_out[b] = m >= min_count ? m : 0;
+    if (i >= m || i >= cap) return;
+    const size_t o = (size_t)b * cap;
+    const int q = query[o + i], t = train[o + i];
+    if (q < 0 || q >= cap || t < 0 || t >= cap) return; // not a match list this library wrote
+    const mslam_keypoint a = kq[o + q], c = kt[o + t];
+    double2* o1 = (double2*)(x1 + (o + i) * 2);
+    double2* o2 = (double2*)(x2 + (o + i) * 2);
+    *o1 = make_double2((double)a.x, (double)a.y);
+    *o2 = make_double2((double)c.x, (double)c.y);
+}
+
+
 extern "C" {
 
 void mslam_fmat_default_params(mslam_fmat_params* p)
@@ -1589,6 +1643,27 @@ int mslam_triangulate_batch(mslam_ctx* ctx, const double* x1, const double* x2, 
     if (front) HIP_TRY(ctx, hipMemcpyAsync(front, base + o_f, N, hipMemcpyDeviceToHost, st));
     if (n_front) HIP_TRY(ctx, hipMemcpyAsync(n_front, base + o_n, sizeof(int32_t) * G, hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
+    return MSLAM_OK;
+}
+
+int mslam_sample_tables_dev(mslam_ctx* ctx, const int32_t* n, const uint64_t* seeds, int H, int k, int B, int32_t* tables)
+{
+    if (!ctx || !n || !seeds || !tables || H < 1 || B < 1 || k < 1 || k > 8) return MSLAM_ERR_INVALID;
+    MSLAM_TRY(ctx_set_device(ctx));
+    hipStream_t st = ctx->stream;
+    hipLaunchKernelGGL(sample_tables_k, dim3((H + 255) / 256, B), dim3(256), 0, st, n, seeds, H, k, tables);
+    HIP_TRY(ctx, hipGetLastError());
+    return MSLAM_OK;
+}
+
+int mslam_gather_matches_dev(mslam_ctx* ctx, const mslam_keypoint* kps_q, const mslam_keypoint* kps_t, int cap, const int32_t* query,
+                             const int32_t* train, const int32_t* count, int B, int min_count, double* x1, double* x2, int32_t* M_out)
+{
+    if (!ctx || !kps_q || !kps_t || !query || !train || !count || !x1 || !x2 || cap < 1 || B < 1) return MSLAM_ERR_INVALID;
+    MSLAM_TRY(ctx_set_device(ctx));
+    hipStream_t st = ctx->stream;
+    hipLaunchKernelGGL(gather_matches_k, dim3((cap + 255) / 256, B), dim3(256), 0, st, kps_q, kps_t, cap, query, train, count, min_count, x1, x2, M_out);
+    HIP_TRY(ctx, hipGetLastError());
     return MSLAM_OK;
 }
 

@@ -1,24 +1,82 @@
 #include "BatchedPipeline.h"
 #include <atomic>
+#include <chrono>
+#include <condition_variable>
 #include <cstring>
+#include <functional>
+#include <mutex>
 #include <stdexcept>
 #include <thread>
 #include "Geometry.h"
 
 namespace {
 
-// run fn(b) for b in [0, n) on the host cores: the per-stream preparation between two batched launches (sample tables,
-// coordinate gathers) is independent per stream
+// run fn(b) for b in [0, n) on the host cores: the per-stream work between two batched launches (sample tables, coordinate
+// gathers, association) is independent per stream.  One pool of workers for the process: a tick calls this several times
+// and starting threads each time costs more than the work.
+class StreamPool {
+public:
+    StreamPool()
+    {
+        const unsigned hw = std::thread::hardware_concurrency();
+        const unsigned nt = std::min<unsigned>(hw ? hw : 1u, 16u);
+        for (unsigned t = 1; t < nt; t++) th_.emplace_back([this]() { loop(); });
+    }
+    ~StreamPool()
+    {
+        { std::lock_guard<std::mutex> l(m_); stop_ = true; gen_++; }
+        cv_.notify_all();
+        for (std::thread& t : th_) t.join();
+    }
+    void run(int n, const std::function<void(int)>& fn)
+    {
+        if (n <= 0) return;
+        if (th_.empty() || n == 1) { for (int b = 0; b < n; b++) fn(b); return; }
+        std::lock_guard<std::mutex> one(run_m_);   // one batch at a time
+        { std::lock_guard<std::mutex> l(m_); fn_ = &fn; n_ = n; next_ = 0; pending_ = (int)th_.size(); err_ = nullptr; gen_++; }
+        cv_.notify_all();
+        work();
+        std::unique_lock<std::mutex> l(m_);
+        done_.wait(l, [&]() { return pending_ == 0; });
+        if (err_) std::rethrow_exception(err_);
+    }
+
+private:
+    void work()
+    {
+        try { for (int b = next_++; b < n_; b = next_++) (*fn_)(b); }
+        catch (...) { std::lock_guard<std::mutex> l(m_); if (!err_) err_ = std::current_exception(); next_ = n_; }
+    }
+    void loop()
+    {
+        unsigned long long seen = 0;
+        for (;;) {
+            { std::unique_lock<std::mutex> l(m_); cv_.wait(l, [&]() { return gen_ != seen; }); seen = gen_; if (stop_) return; }
+            work();
+            { std::lock_guard<std::mutex> l(m_); if (--pending_ == 0) done_.notify_one(); }
+        }
+    }
+    std::vector<std::thread> th_;
+    std::mutex m_, run_m_;
+    std::condition_variable cv_, done_;
+    const std::function<void(int)>* fn_ = nullptr;
+    std::atomic<int> next_{ 0 };
+    int n_ = 0, pending_ = 0;
+    unsigned long long gen_ = 0;
+    bool stop_ = false;
+    std::exception_ptr err_;
+};
 template <typename F> void parallelStreams(int n, F fn)
 {
-    const unsigned hw = std::thread::hardware_concurrency();
-    const int nt = (int)std::min<unsigned>(std::min<unsigned>(hw ? hw : 1u, 16u), (unsigned)n);
-    if (nt <= 1) { for (int b = 0; b < n; b++) fn(b); return; }
-    std::atomic<int> next(0);
-    std::vector<std::thread> th;
-    for (int t = 0; t < nt; t++) th.emplace_back([&]() { for (int b = next++; b < n; b = next++) fn(b); });
-    for (std::thread& t : th) t.join();
+    static StreamPool pool;
+    pool.run(n, std::function<void(int)>(fn));
 }
+
+struct PhaseTimer {   // adds the scope's wall time to one accumulator
+    double& acc; std::chrono::steady_clock::time_point t0;
+    explicit PhaseTimer(double& a) : acc(a), t0(std::chrono::steady_clock::now()) {}
+    ~PhaseTimer() { acc += 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
+};
 
 void chk(int status, const char* what)
 {
@@ -51,12 +109,19 @@ BatchedPipeline::BatchedPipeline(std::vector<DataManager*> streams, const Featur
     lastStatus.assign(dms_.size(), MSLAM_OK);
 }
 
+const char* BatchedPipeline::phaseName(int p)
+{
+    static const char* const names[PH_COUNT] = { "stage_frames", "extract", "features_down", "match", "fmat_prep", "fmat", "associate", "pnp_prep", "pnp", "triangulate" };
+    return (p >= 0 && p < PH_COUNT) ? names[p] : "";
+}
+
 BatchedPipeline::~BatchedPipeline()
 {
     if (runner_) {
         runner_->sync();
         for (int i = 0; i < 4; i++) if (dscratch_[i]) (void)mslam_dev_free(runner_->ctx(), dscratch_[i]);
         if (pinned_) (void)mslam_host_free(runner_->ctx(), pinned_);
+        if (arena_) (void)mslam_host_free(runner_->ctx(), arena_);
     }
 }
 
@@ -81,38 +146,56 @@ void BatchedPipeline::extractAll(int frameIdx)
         w_ = f0.cols; h_ = f0.rows; ch_ = f0.channels();
         MultiStreamRunner::Config cfg;
         cfg.device = device_; cfg.streams = B; cfg.w = w_; cfg.h = h_; cfg.channels = ch_; cfg.orb = fe_.params;
-        cfg.capacitySlack = fe_.capacitySlack; cfg.ring = ring_; cfg.frameSets = 2; cfg.pnpOnSecondStream = false;
+        cfg.capacitySlack = fe_.capacitySlack; cfg.ring = ring_; cfg.frameSets = 2; cfg.matchSets = ring_ - 1; cfg.pnpOnSecondStream = false;
         runner_.reset(new MultiStreamRunner(cfg));
         pinned_bytes_ = (size_t)w_ * ch_ * h_ * B;
         chk(mslam_host_alloc(runner_->ctx(), &pinned_, pinned_bytes_), "mslam_host_alloc");
     }
     const size_t row = (size_t)w_ * ch_, fb = row * h_;
-    for (int b = 0; b < B; b++) {
-        const cv::Mat& img = dms_[(size_t)b]->frames.at((size_t)frameIdx).frameBuffer;
-        if (img.cols != w_ || img.rows != h_ || img.channels() != ch_) throw std::runtime_error("BatchedPipeline: all streams must share one frame geometry");
-        for (int y = 0; y < h_; y++) std::memcpy((uint8_t*)pinned_ + (size_t)b * fb + (size_t)y * row, img.data + img.step * (size_t)y, row);
+    {
+        PhaseTimer pt(phaseMs[PH_STAGE_FRAMES]);
+        for (int b = 0; b < B; b++) {
+            const cv::Mat& img = dms_[(size_t)b]->frames.at((size_t)frameIdx).frameBuffer;
+            if (img.cols != w_ || img.rows != h_ || img.channels() != ch_) throw std::runtime_error("BatchedPipeline: all streams must share one frame geometry");
+        }
+        parallelStreams(B, [&](int b) {
+            const cv::Mat& img = dms_[(size_t)b]->frames[(size_t)frameIdx].frameBuffer;
+            for (int y = 0; y < h_; y++) std::memcpy((uint8_t*)pinned_ + (size_t)b * fb + (size_t)y * row, img.data + img.step * (size_t)y, row);
+        });
     }
     const int set = frameIdx & 1, slot = slotOf(frameIdx);
-    runner_->uploadFramesAsync(set, (const uint8_t*)pinned_);
-    runner_->extract(set, slot);
     std::vector<int32_t> n, st;
-    runner_->downloadCounts(slot, n, &st);   // syncs: the pinned buffer may be refilled from here on
+    {
+        PhaseTimer pt(phaseMs[PH_EXTRACT]);
+        runner_->uploadFramesAsync(set, (const uint8_t*)pinned_);
+        runner_->extract(set, slot);
+        runner_->downloadCounts(slot, n, &st);   // syncs: the pinned buffer may be refilled from here on
+    }
+    PhaseTimer pt(phaseMs[PH_FEATURES_DOWN]);
     const int cap = runner_->cap();
-    std::vector<mslam_keypoint> kps;
-    for (int b = 0; b < B; b++) {
-        chk(st[(size_t)b], "mslam_orb_extract_batch_dev (per-frame status)");
+    for (int b = 0; b < B; b++) chk(st[(size_t)b], "mslam_orb_extract_batch_dev (per-frame status)");
+    std::vector<mslam_keypoint> all;
+    runner_->downloadKeypoints(slot, all);   // one copy for the B streams
+    parallelStreams(B, [&](int b) {
         Frame& frame = dms_[(size_t)b]->frames[(size_t)frameIdx];
         const int nb = n[(size_t)b];
-        cv::Mat desc;
-        if (eagerDescriptors) { desc.create(nb, 32, cv::CV_8U); runner_->downloadFeatures(slot, b, nb, kps, desc.data); }
-        else runner_->downloadFeatures(slot, b, nb, kps, nullptr);
-        frame.features.descriptors = desc;   // empty unless eager: descriptors(stream, frame) fills it on demand
+        const mslam_keypoint* kps = all.data() + (size_t)b * cap;
+        frame.features.positions.reserve((size_t)nb); frame.features.scales.reserve((size_t)nb);
         for (int i = 0; i < nb; i++) {
-            frame.features.positions.push_back(Point2d(cv::Point2f(kps[(size_t)i].x, kps[(size_t)i].y)));   // Point2f -> Point2d widening
-            frame.features.scales.push_back((double)kps[(size_t)i].size);
+            frame.features.positions.push_back(Point2d(cv::Point2f(kps[i].x, kps[i].y)));   // Point2f -> Point2d widening
+            frame.features.scales.push_back((double)kps[i].size);
         }
         frame.features.mapPointsIndices.resize((size_t)nb, -1);
-        (void)cap;
+    });
+    for (int b = 0; b < B; b++) {
+        Frame& frame = dms_[(size_t)b]->frames[(size_t)frameIdx];
+        cv::Mat desc;   // empty unless eager: descriptors(stream, frame) fills it on demand
+        if (eagerDescriptors) {
+            std::vector<mslam_keypoint> kps;
+            desc.create(n[(size_t)b], 32, cv::CV_8U);
+            runner_->downloadFeatures(slot, b, n[(size_t)b], kps, desc.data);
+        }
+        frame.features.descriptors = desc;
     }
 }
 
@@ -131,62 +214,65 @@ const cv::Mat& BatchedPipeline::descriptors(int stream, int frameIdx)
     return frame.features.descriptors;
 }
 
-void BatchedPipeline::matchAll(int slotQ, int slotT, float ratio, MatchSet& out)
+// matchFeatures (src/CameraPoseEstimator.cpp:200-213) + computeFundamentalMatrix (:545-586) of slot slotQ against each of
+// slotsT, for all streams: N = slotsT.size() x B problems in ONE launch sequence with ONE synchronisation.  Nothing is
+// assembled on the host: the matched coordinates are gathered from the resident keypoints (mslam_gather_matches_dev), the
+// sample tables are drawn on the device (mslam_sample_tables_dev == geom::sampleTable), and the match lists, inlier masks
+// and F come back through one pinned buffer.
+void BatchedPipeline::matchFilterMany(int slotQ, const std::vector<int>& slotsT, float ratio, const std::vector<uint64_t>& seeds, Filtered& out)
 {
-    runner_->match(slotQ, slotT, ratio);
-    runner_->downloadMatches(out.count, out.query, out.train, out.dist);
-}
-
-// computeFundamentalMatrix (src/CameraPoseEstimator.cpp:545-586) for the B match sets in one launch sequence
-void BatchedPipeline::fmatAll(const std::vector<const Frame*>& fq, const std::vector<const Frame*>& ft, const MatchSet& ms,
-                              const std::vector<uint64_t>& seeds, std::vector<double>& F, std::vector<std::vector<uint8_t>>& status, std::vector<int>& rc)
-{
-    const int B = streams(), cap = runner_->cap(), H = cpe_.fmatHypotheses;
-    int capM = 8;
-    for (int b = 0; b < B; b++) capM = std::max(capM, ms.count[(size_t)b]);
-    std::vector<double> x1((size_t)B * capM * 2, 0.0), x2((size_t)B * capM * 2, 0.0);
-    std::vector<int32_t> M((size_t)B, 0), S((size_t)B * H * 8, 0);
-    rc.assign((size_t)B, MSLAM_OK);
-    parallelStreams(B, [&](int b) {
-        const int m = ms.count[(size_t)b];
-        if (m < 8) { rc[(size_t)b] = MSLAM_ERR_TOO_FEW; return; }   // the kernels see M = 0 for this stream and skip it
-        M[(size_t)b] = m;
-        for (int i = 0; i < m; i++) {
-            const Point2d& a = fq[(size_t)b]->features.positions[(size_t)ms.query[(size_t)b * cap + i]];
-            const Point2d& c = ft[(size_t)b]->features.positions[(size_t)ms.train[(size_t)b * cap + i]];
-            x1[((size_t)b * capM + i) * 2] = a.x; x1[((size_t)b * capM + i) * 2 + 1] = a.y;
-            x2[((size_t)b * capM + i) * 2] = c.x; x2[((size_t)b * capM + i) * 2 + 1] = c.y;
-        }
-        const std::vector<int32_t> t = geom::sampleTable(m, H, 8, seeds[(size_t)b]);
-        std::memcpy(&S[(size_t)b * H * 8], t.data(), sizeof(int32_t) * t.size());
-    });
+    const int B = streams(), cap = runner_->cap(), H = cpe_.fmatHypotheses, nb = (int)slotsT.size(), N = nb * B;
     mslam_ctx* ctx = runner_->ctx();
-    const size_t nx = sizeof(double) * (size_t)B * capM * 2, nS = sizeof(int32_t) * (size_t)B * H * 8;
     auto up256 = [](size_t v) { return (v + 255) & ~(size_t)255; };
-    uint8_t* in = (uint8_t*)scratch(0, up256(nx) * 2 + up256(nS) + 256 + 256 * (size_t)B);
-    double* dx1 = (double*)in; double* dx2 = (double*)(in + up256(nx));
-    int32_t* dS = (int32_t*)(in + 2 * up256(nx)); int32_t* dM = (int32_t*)(in + 2 * up256(nx) + up256(nS));
-    uint8_t* outb = (uint8_t*)scratch(1, up256(sizeof(double) * 9 * B) + up256((size_t)B * capM) + 1024 * (size_t)B + 4096);
-    double* dF = (double*)outb; uint8_t* dst = outb + up256(sizeof(double) * 9 * B);
-    int32_t* dbest = (int32_t*)(dst + up256((size_t)B * capM)); int32_t* dninl = dbest + B;
-    chk(mslam_memcpy_h2d(ctx, dx1, x1.data(), nx), "mslam_memcpy_h2d");
-    chk(mslam_memcpy_h2d(ctx, dx2, x2.data(), nx), "mslam_memcpy_h2d");
-    chk(mslam_memcpy_h2d(ctx, dS, S.data(), nS), "mslam_memcpy_h2d");
-    chk(mslam_memcpy_h2d(ctx, dM, M.data(), sizeof(int32_t) * B), "mslam_memcpy_h2d");
-    chk(mslam_fmat_ransac8_batch_dev(ctx, dx1, dx2, dM, capM, dS, H, B, &cpe_.fmat, dF, dst, nullptr, dbest, dninl), "mslam_fmat_ransac8_batch_dev");
-    F.assign((size_t)B * 9, 0.0);
-    std::vector<uint8_t> st((size_t)B * capM);
-    std::vector<int32_t> best((size_t)B);
-    chk(mslam_memcpy_d2h_async(ctx, F.data(), dF, sizeof(double) * 9 * B), "mslam_memcpy_d2h_async");
-    chk(mslam_memcpy_d2h_async(ctx, st.data(), dst, (size_t)B * capM), "mslam_memcpy_d2h_async");
-    chk(mslam_memcpy_d2h(ctx, best.data(), dbest, sizeof(int32_t) * B), "mslam_memcpy_d2h");
-    status.assign((size_t)B, {});
-    for (int b = 0; b < B; b++) {
-        const int m = ms.count[(size_t)b];
-        status[(size_t)b].assign((size_t)m, 0);
-        if (rc[(size_t)b] != MSLAM_OK) continue;
-        if (best[(size_t)b] < 0) { rc[(size_t)b] = MSLAM_ERR_DEGENERATE; continue; }
-        std::memcpy(status[(size_t)b].data(), &st[(size_t)b * capM], (size_t)m);
+    const size_t nl = (size_t)N * cap;
+    // device scratch: x1, x2, tables, M, seeds | F, status, best, ninl
+    const size_t o_x2 = up256(sizeof(double) * nl * 2), o_S = 2 * o_x2, o_M = o_S + up256(sizeof(int32_t) * (size_t)N * H * 8), o_sd = o_M + up256(sizeof(int32_t) * N);
+    uint8_t* in = (uint8_t*)scratch(0, o_sd + up256(sizeof(uint64_t) * N));
+    double* dx1 = (double*)in; double* dx2 = (double*)(in + o_x2);
+    int32_t* dS = (int32_t*)(in + o_S); int32_t* dM = (int32_t*)(in + o_M); uint64_t* dseed = (uint64_t*)(in + o_sd);
+    const size_t o_st = up256(sizeof(double) * 9 * N), o_best = o_st + up256(nl);
+    uint8_t* outb = (uint8_t*)scratch(1, o_best + up256(sizeof(int32_t) * 2 * N));
+    double* dF = (double*)outb; uint8_t* dst = outb + o_st; int32_t* dbest = (int32_t*)(outb + o_best); int32_t* dninl = dbest + N;
+    // pinned arena: seeds (up) | query, train, dist, count, status, F, best (down)
+    const size_t h_q = up256(sizeof(uint64_t) * N), h_t = h_q + up256(4 * nl), h_d = h_t + up256(4 * nl), h_c = h_d + up256(4 * nl), h_st = h_c + up256(4 * (size_t)N),
+                 h_F = h_st + up256(nl), h_b = h_F + up256(sizeof(double) * 9 * N), h_end = h_b + up256(4 * (size_t)N);
+    if (h_end > arena_bytes_) {
+        if (arena_) chk(mslam_host_free(ctx, arena_), "mslam_host_free");
+        arena_ = nullptr; arena_bytes_ = 0;
+        chk(mslam_host_alloc(ctx, &arena_, h_end + h_end / 4), "mslam_host_alloc");
+        arena_bytes_ = h_end + h_end / 4;
+    }
+    uint8_t* hp = (uint8_t*)arena_;
+    {
+        PhaseTimer pt(phaseMs[PH_MATCH]);
+        std::memcpy(hp, seeds.data(), sizeof(uint64_t) * N);
+        chk(mslam_memcpy_h2d_async(ctx, dseed, hp, sizeof(uint64_t) * N), "mslam_memcpy_h2d_async");
+        for (int k = 0; k < nb; k++) runner_->match(slotQ, slotsT[(size_t)k], ratio, k);   // enqueued back to back
+        for (int k = 0; k < nb; k++) {
+            const size_t o = (size_t)k * B * cap;
+            chk(mslam_gather_matches_dev(ctx, runner_->kpsDev(slotQ), runner_->kpsDev(slotsT[(size_t)k]), cap, runner_->matchQueryDev() + o, runner_->matchTrainDev() + o,
+                                         runner_->matchCountDev() + (size_t)k * B, B, 8, dx1 + o * 2, dx2 + o * 2, dM + (size_t)k * B), "mslam_gather_matches_dev");
+        }
+        chk(mslam_sample_tables_dev(ctx, dM, dseed, H, 8, N, dS), "mslam_sample_tables_dev");
+    }
+    PhaseTimer pt(phaseMs[PH_FMAT]);
+    chk(mslam_fmat_ransac8_batch_dev(ctx, dx1, dx2, dM, cap, dS, H, N, &cpe_.fmat, dF, dst, nullptr, dbest, dninl), "mslam_fmat_ransac8_batch_dev");
+    chk(mslam_memcpy_d2h_async(ctx, hp + h_q, runner_->matchQueryDev(), 4 * nl), "mslam_memcpy_d2h_async");
+    chk(mslam_memcpy_d2h_async(ctx, hp + h_t, runner_->matchTrainDev(), 4 * nl), "mslam_memcpy_d2h_async");
+    chk(mslam_memcpy_d2h_async(ctx, hp + h_d, runner_->matchDistDev(), 4 * nl), "mslam_memcpy_d2h_async");
+    chk(mslam_memcpy_d2h_async(ctx, hp + h_c, runner_->matchCountDev(), 4 * (size_t)N), "mslam_memcpy_d2h_async");
+    chk(mslam_memcpy_d2h_async(ctx, hp + h_st, dst, nl), "mslam_memcpy_d2h_async");
+    chk(mslam_memcpy_d2h_async(ctx, hp + h_F, dF, sizeof(double) * 9 * N), "mslam_memcpy_d2h_async");
+    chk(mslam_memcpy_d2h_async(ctx, hp + h_b, dbest, 4 * (size_t)N), "mslam_memcpy_d2h_async");
+    chk(mslam_sync(ctx), "mslam_sync");   // the only synchronisation of the stage
+    out.cap = cap;
+    out.query = (const int32_t*)(hp + h_q); out.train = (const int32_t*)(hp + h_t); out.dist = (const float*)(hp + h_d);
+    out.count = (const int32_t*)(hp + h_c); out.status = hp + h_st; out.F = (const double*)(hp + h_F);
+    const int32_t* best = (const int32_t*)(hp + h_b);
+    out.rc.assign((size_t)N, MSLAM_OK);
+    for (int q = 0; q < N; q++) {
+        if (out.count[q] < 8) out.rc[(size_t)q] = MSLAM_ERR_TOO_FEW;          // status of such a set is not meaningful: inlier() says 0
+        else if (best[q] < 0) out.rc[(size_t)q] = MSLAM_ERR_DEGENERATE;
     }
 }
 
@@ -194,15 +280,11 @@ void BatchedPipeline::fmatAll(const std::vector<const Frame*>& fq, const std::ve
 void BatchedPipeline::poseInitial(int frameIdx)
 {
     const int B = streams(), cap = runner_->cap();
-    MatchSet ms;
-    matchAll(slotOf(frameIdx - 1), slotOf(frameIdx), cpe_.ratioInitial, ms);   // query = previous frame, train = current (:280)
-    std::vector<const Frame*> fq((size_t)B), ft((size_t)B);
+    Filtered ms;
     std::vector<uint64_t> seeds((size_t)B, cpe_.seed + 1000ull * (uint64_t)frameIdx);
-    for (int b = 0; b < B; b++) { fq[(size_t)b] = &dms_[(size_t)b]->frames[(size_t)frameIdx - 1]; ft[(size_t)b] = &dms_[(size_t)b]->frames[(size_t)frameIdx]; }
-    std::vector<double> F;
-    std::vector<std::vector<uint8_t>> status;
-    std::vector<int> rc;
-    fmatAll(fq, ft, ms, seeds, F, status, rc);
+    matchFilterMany(slotOf(frameIdx - 1), { slotOf(frameIdx) }, cpe_.ratioInitial, seeds, ms);   // query = previous frame, train = current (:280)
+    const std::vector<int>& rc = ms.rc;
+    const double* F = ms.F;
     // per stream: inlier coordinates and the four (R, t) candidates in the reference's order (R1|t1, R1|t2, R2|t1, R2|t2);
     // ONE batched triangulation for all 4 B candidate groups, then the vote per stream (:337-354)
     struct Init { bool ok = false; std::vector<double> x1, x2; double K1[9], K2[9], cand[4][12]; };
@@ -217,7 +299,7 @@ void BatchedPipeline::poseInitial(int frameIdx)
         Init& s0 = in[(size_t)b];
         const int m = ms.count[(size_t)b];
         for (int i = 0; i < m; i++)
-            if (status[(size_t)b][(size_t)i]) {
+            if (ms.inlier(b, i)) {
                 const Point2d& a = pre.features.positions[(size_t)ms.query[(size_t)b * cap + i]];
                 const Point2d& c = cur.features.positions[(size_t)ms.train[(size_t)b * cap + i]];
                 s0.x1.push_back(a.x); s0.x1.push_back(a.y); s0.x2.push_back(c.x); s0.x2.push_back(c.y);
@@ -267,7 +349,7 @@ void BatchedPipeline::poseInitial(int frameIdx)
         int count = 0;
         const int m = ms.count[(size_t)b];
         for (int i = 0; i < m; i++)
-            if (status[(size_t)b][(size_t)i] == 1) {
+            if (ms.inlier(b, i) == 1) {
                 registerNewMapPoint(data, Point3d(bestX[3 * (size_t)count], bestX[3 * (size_t)count + 1], bestX[3 * (size_t)count + 2]), pre,
                                     ms.query[(size_t)b * cap + i], cur, ms.train[(size_t)b * cap + i]);
                 count++;
@@ -288,75 +370,82 @@ void BatchedPipeline::posePnp(int frameIdx)
         ps[(size_t)b].numCur = (int)dms_[(size_t)b]->frames[(size_t)frameIdx].features.positions.size();
         ps[(size_t)b].matched.assign((size_t)ps[(size_t)b].numCur, false);
     }
-    for (int i = frameIdx - 1; i >= 0 && i >= frameIdx - cpe_.numBackTraverse; i--) {
-        MatchSet ms;
-        matchAll(slotOf(frameIdx), slotOf(i), cpe_.ratioTracking, ms);   // query = current, train = previous frame i (:405-409)
-        std::vector<const Frame*> fq((size_t)B), ft((size_t)B);
-        std::vector<uint64_t> seeds((size_t)B, cpe_.seed + 1000ull * (uint64_t)frameIdx + (uint64_t)(frameIdx - i));
-        for (int b = 0; b < B; b++) {
-            fq[(size_t)b] = &dms_[(size_t)b]->frames[(size_t)frameIdx]; ft[(size_t)b] = &dms_[(size_t)b]->frames[(size_t)i];
-            if (ps[(size_t)b].done) ms.count[(size_t)b] = 0;   // this stream left the back-traverse loop already (:456)
-        }
-        std::vector<double> F;
-        std::vector<std::vector<uint8_t>> status;
-        std::vector<int> rc;
-        fmatAll(fq, ft, ms, seeds, F, status, rc);   // epipolar filter (FILTERING_WITH_F, :412-427): F itself is discarded
-        for (int b = 0; b < B; b++) {
+    // The match and the epipolar filter of the current frame against each back frame do not depend on the association
+    // state, so all of them go out in one launch sequence (N = back frames x streams problems); the association below
+    // then walks the back frames in the reference's order per stream and stops where the reference's loop stops (:456).
+    std::vector<int> backs, backSlots;
+    for (int i = frameIdx - 1; i >= 0 && i >= frameIdx - cpe_.numBackTraverse; i--) { backs.push_back(i); backSlots.push_back(slotOf(i)); }
+    const int nb = (int)backs.size(), N = nb * B;
+    std::vector<uint64_t> seeds((size_t)N);
+    for (int k = 0; k < nb; k++)
+        for (int b = 0; b < B; b++) seeds[(size_t)k * B + b] = cpe_.seed + 1000ull * (uint64_t)frameIdx + (uint64_t)(frameIdx - backs[(size_t)k]);
+    Filtered ms;   // query = current, train = previous frame i (:405-409); epipolar filter (FILTERING_WITH_F, :412-427): F itself is discarded
+    matchFilterMany(slotOf(frameIdx), backSlots, cpe_.ratioTracking, seeds, ms);
+    const std::vector<int>& rc = ms.rc;
+    {
+        PhaseTimer pt(phaseMs[PH_ASSOCIATE]);
+        parallelStreams(B, [&](int b) {
             PerStream& s = ps[(size_t)b];
-            if (s.done) continue;
             DataManager& data = *dms_[(size_t)b];
             Frame& cur = data.frames[(size_t)frameIdx];
-            Features& preF = data.frames[(size_t)i].features;
-            if (rc[(size_t)b] != MSLAM_OK) lastStatus[(size_t)b] = rc[(size_t)b];
-            std::vector<cv::DMatch> raw;
-            for (int j = 0; j < ms.count[(size_t)b]; j++)
-                if (status[(size_t)b][(size_t)j]) {
-                    cv::DMatch m; m.queryIdx = ms.query[(size_t)b * cap + j]; m.trainIdx = ms.train[(size_t)b * cap + j]; m.distance = ms.dist[(size_t)b * cap + j];
-                    raw.push_back(m);
+            for (int k = 0; k < nb && !s.done; k++) {
+                const size_t q = (size_t)k * B + b;
+                Features& preF = data.frames[(size_t)backs[(size_t)k]].features;
+                if (rc[q] != MSLAM_OK) lastStatus[(size_t)b] = rc[q];
+                std::vector<cv::DMatch> raw;
+                for (int j = 0; j < ms.count[q]; j++)
+                    if (ms.inlier((int)q, j)) {
+                        cv::DMatch m; m.queryIdx = ms.query[q * cap + j]; m.trainIdx = ms.train[q * cap + j]; m.distance = ms.dist[q * cap + j];
+                        raw.push_back(m);
+                    }
+                s.cachedMatches.push_back(raw);
+                for (size_t j = 0; j < raw.size(); j++) {
+                    const int cf = raw[j].queryIdx, pf = raw[j].trainIdx;
+                    if (preF.mapPointsIndices[(size_t)pf] != -1 && !s.matched[(size_t)cf]) {
+                        s.count++;
+                        s.matched[(size_t)cf] = true;
+                        const int mp = preF.mapPointsIndices[(size_t)pf];
+                        associate(data, mp, cur, cf);
+                        s.mapPoints.push_back(data.mapPoints[(size_t)mp].worldPosition);
+                        s.imagePoints.push_back(cur.features.positions[(size_t)cf]);
+                        if (s.count == s.numCur) break;
+                    }
                 }
-            s.cachedMatches.push_back(raw);
-            for (size_t j = 0; j < raw.size(); j++) {
-                const int cf = raw[j].queryIdx, pf = raw[j].trainIdx;
-                if (preF.mapPointsIndices[(size_t)pf] != -1 && !s.matched[(size_t)cf]) {
-                    s.count++;
-                    s.matched[(size_t)cf] = true;
-                    const int mp = preF.mapPointsIndices[(size_t)pf];
-                    associate(data, mp, cur, cf);
-                    s.mapPoints.push_back(data.mapPoints[(size_t)mp].worldPosition);
-                    s.imagePoints.push_back(cur.features.positions[(size_t)cf]);
-                    if (s.count == s.numCur) break;
-                }
+                if (s.count == s.numCur) s.done = true;
             }
-            if (s.count == s.numCur) s.done = true;
-        }
+        });
     }
     // ---- solvePnPRansac for all streams (:472)
     const int H = cpe_.pnpHypotheses;
     int capP = 4;
     for (int b = 0; b < B; b++) capP = std::max(capP, (int)ps[(size_t)b].mapPoints.size());
     std::vector<double> X((size_t)B * capP * 3, 0.0), x((size_t)B * capP * 2, 0.0), K((size_t)B * 9), D((size_t)B * 8);
-    std::vector<int32_t> P((size_t)B, 0), S((size_t)B * H * 4, 0);
-    for (int b = 0; b < B; b++) {
+    std::vector<int32_t> P((size_t)B, 0);
+    std::vector<uint64_t> pnpSeeds((size_t)B, cpe_.seed + 1000ull * (uint64_t)frameIdx + 99);
+    const auto tprep = std::chrono::steady_clock::now();
+    parallelStreams(B, [&](int b) {
         const PerStream& s = ps[(size_t)b];
         Frame& cur = dms_[(size_t)b]->frames[(size_t)frameIdx];
         cur.Rt = dms_[(size_t)b]->frames[(size_t)frameIdx - 1].Rt.clone(); // kept if PnP cannot be solved
         matTo(cur.K, &K[(size_t)b * 9], 9);
         std::memcpy(&D[(size_t)b * 8], cpe_.distCoeff, sizeof(double) * 8);
         const int p = (int)s.mapPoints.size();
-        if (p < 4) { lastStatus[(size_t)b] = MSLAM_ERR_TOO_FEW; continue; }
+        if (p < 4) { lastStatus[(size_t)b] = MSLAM_ERR_TOO_FEW; return; }
         P[(size_t)b] = p;
         for (int i = 0; i < p; i++) {
             X[((size_t)b * capP + i) * 3] = s.mapPoints[(size_t)i].x; X[((size_t)b * capP + i) * 3 + 1] = s.mapPoints[(size_t)i].y; X[((size_t)b * capP + i) * 3 + 2] = s.mapPoints[(size_t)i].z;
             x[((size_t)b * capP + i) * 2] = s.imagePoints[(size_t)i].x; x[((size_t)b * capP + i) * 2 + 1] = s.imagePoints[(size_t)i].y;
         }
-        const std::vector<int32_t> t = geom::sampleTable(p, H, 4, cpe_.seed + 1000ull * (uint64_t)frameIdx + 99);
-        std::memcpy(&S[(size_t)b * H * 4], t.data(), sizeof(int32_t) * t.size());
-    }
-    runner_->setPnpProblems(capP, H, X.data(), x.data(), P.data(), K.data(), D.data(), S.data(), cpe_.pnp);
-    runner_->pnp();
+    });
+    phaseMs[PH_PNP_PREP] += 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - tprep).count();
     std::vector<double> Rt;
     std::vector<int32_t> best, ninl;
-    runner_->downloadPnp(Rt, best, ninl);
+    {
+        PhaseTimer pt(phaseMs[PH_PNP]);
+        runner_->setPnpProblems(capP, H, X.data(), x.data(), P.data(), K.data(), D.data(), nullptr, cpe_.pnp, pnpSeeds.data());   // tables drawn on the device
+        runner_->pnp();
+        runner_->downloadPnp(Rt, best, ninl);
+    }
     for (int b = 0; b < B; b++) {
         if (P[(size_t)b] < 4) continue;
         if (best[(size_t)b] >= 0 && ninl[(size_t)b] >= cpe_.pnp.min_inliers) dms_[(size_t)b]->frames[(size_t)frameIdx].Rt = matFrom(&Rt[(size_t)b * 12], 3, 4);
@@ -365,6 +454,7 @@ void BatchedPipeline::posePnp(int frameIdx)
     // ---- triangulate the matches not yet tied to a map point, against each previous frame (:488-512): per back frame one
     // batched call over the streams (the association state of a stream advances from one back frame to the next, so the
     // back frames stay sequential)
+    PhaseTimer ptTri(phaseMs[PH_TRIANGULATE]);
     for (int i = frameIdx - 1; i >= 0 && i >= frameIdx - cpe_.numBackTraverse; i--) {
         const size_t mi = (size_t)(frameIdx - 1 - i);
         std::vector<double> gx1, gx2, gRt1, gRt2, gK1, gK2;

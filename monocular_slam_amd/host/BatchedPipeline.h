@@ -33,16 +33,27 @@ public:
     std::vector<int> lastStatus;       // per stream: MSLAM_OK or the status that made the pose stage keep the previous pose
     MultiStreamRunner* runner() { return runner_.get(); }
     bool eagerDescriptors = false;     // true: fill Frame.features.descriptors for every frame right after extraction
+    // host wall time per phase, accumulated over the ticks (milliseconds; device work counts where the host waits for it)
+    enum Phase { PH_STAGE_FRAMES, PH_EXTRACT, PH_FEATURES_DOWN, PH_MATCH, PH_FMAT_PREP, PH_FMAT, PH_ASSOCIATE, PH_PNP_PREP, PH_PNP, PH_TRIANGULATE, PH_COUNT };
+    double phaseMs[PH_COUNT] = { 0 };
+    static const char* phaseName(int p);
 
 private:
     void extractAll(int frameIdx);
     void poseInitial(int frameIdx);
     void posePnp(int frameIdx);
-    struct MatchSet { std::vector<int32_t> count, query, train; std::vector<float> dist; };
-    void matchAll(int slotQ, int slotT, float ratio, MatchSet& out);
-    // F RANSAC over the B match sets: x1 = positions of the query frame, x2 = of the train frame
-    void fmatAll(const std::vector<const Frame*>& fq, const std::vector<const Frame*>& ft, const MatchSet& ms, const std::vector<uint64_t>& seeds,
-                 std::vector<double>& F, std::vector<std::vector<uint8_t>>& status, std::vector<int>& rc);
+    // match lists + epipolar inlier masks of N = sets x B problems (problem k * B + b = set k, stream b), viewed in the pinned
+    // download buffer: valid until the next matchFilterMany
+    struct Filtered {
+        int cap = 0;
+        const int32_t *count = nullptr, *query = nullptr, *train = nullptr;   // N, N x cap, N x cap
+        const float* dist = nullptr;                                           // N x cap
+        const uint8_t* status = nullptr;                                       // N x cap
+        const double* F = nullptr;                                             // N x 9
+        std::vector<int> rc;                                                   // N: MSLAM_OK / TOO_FEW / DEGENERATE
+        uint8_t inlier(int q, int i) const { return rc[(size_t)q] == MSLAM_OK ? status[(size_t)q * cap + i] : 0; }
+    };
+    void matchFilterMany(int slotQ, const std::vector<int>& slotsT, float ratio, const std::vector<uint64_t>& seeds, Filtered& out);
     int slotOf(int frameIdx) const { return frameIdx % ring_; }
     void* scratch(int slot, size_t bytes);
 
@@ -52,5 +63,6 @@ private:
     int device_, ring_, w_ = 0, h_ = 0, ch_ = 0;
     std::unique_ptr<MultiStreamRunner> runner_;
     void* pinned_ = nullptr; size_t pinned_bytes_ = 0;
+    void* arena_ = nullptr; size_t arena_bytes_ = 0;   // pinned up/download buffer of matchFilterMany
     void* dscratch_[4] = { nullptr, nullptr, nullptr, nullptr }; size_t dscratch_bytes_[4] = { 0, 0, 0, 0 };
 };

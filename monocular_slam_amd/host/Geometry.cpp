@@ -249,11 +249,21 @@ bool ldltSolve(const double* S, int n, const double* rhs, double* x)
     return true;
 }
 
+uint64_t splitmix64(uint64_t z)
+{
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+// Rows are independent (row h has its own generator state), so mslam_sample_tables_dev can draw one row per thread and
+// give the same table.
 std::vector<int32_t> sampleTable(int n, int H, int k, uint64_t seed)
 {
-    std::vector<int32_t> out((size_t)H * k);
-    Rng rng(seed);
-    for (int h = 0; h < H; h++)
+    std::vector<int32_t> out((size_t)H * k, 0);
+    if (n < k) return out;
+    for (int h = 0; h < H; h++) {
+        Rng rng(splitmix64(seed + (uint64_t)(h + 1) * 0x9E3779B97F4A7C15ull));
         for (int i = 0; i < k; i++) {
             int32_t v;
             bool dup;
@@ -264,6 +274,7 @@ std::vector<int32_t> sampleTable(int n, int H, int k, uint64_t seed)
             } while (dup);
             out[(size_t)h * k + i] = v;
         }
+    }
     return out;
 }
 

@@ -40,7 +40,9 @@ struct Rng {
     uint64_t next() { s ^= s >> 12; s ^= s << 25; s ^= s >> 27; return s * 0x2545F4914F6CDD1Dull; }
     uint32_t below(uint32_t n) { return (uint32_t)((next() >> 32) % n); }
 };
-// H rows of k distinct indices in [0, n)
+uint64_t splitmix64(uint64_t z);
+// H rows of k distinct indices in [0, n): row h is drawn by Rng(splitmix64(seed + (h + 1) * 0x9E3779B97F4A7C15)) with repeats
+// within the row redrawn (zero table if n < k).  mslam_sample_tables_dev (include/mslam.h) generates the same table on the device.
 std::vector<int32_t> sampleTable(int n, int H, int k, uint64_t seed);
 
 } // namespace geom

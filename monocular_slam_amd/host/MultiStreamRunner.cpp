@@ -12,7 +12,7 @@ void MultiStreamRunner::check(int status, const char* what, mslam_ctx* c) const
 
 MultiStreamRunner::MultiStreamRunner(const Config& cfg) : cfg_(cfg)
 {
-    if (cfg.streams < 1 || cfg.ring < 2 || cfg.frameSets < 1) throw std::runtime_error("MultiStreamRunner: bad configuration");
+    if (cfg.streams < 1 || cfg.ring < 2 || cfg.frameSets < 1 || cfg.matchSets < 1) throw std::runtime_error("MultiStreamRunner: bad configuration");
     const int B = cfg.streams;
     cap_ = cfg.orb.nfeatures + cfg.capacitySlack;
     const int max_kpts = cap_ < 4096 ? 4096 : cap_;
@@ -31,12 +31,13 @@ MultiStreamRunner::MultiStreamRunner(const Config& cfg) : cfg_(cfg)
         check(mslam_memcpy_h2d(ctx_, n_.back(), z.data(), sizeof(int32_t) * B), "mslam_memcpy_h2d", ctx_);
     }
     status_ = (int32_t*)alloc(sizeof(int32_t) * B);
-    idx_ = (int32_t*)alloc(sizeof(int32_t) * (size_t)B * cap_ * 2);
-    dist_ = (int32_t*)alloc(sizeof(int32_t) * (size_t)B * cap_ * 2);
-    mq_ = (int32_t*)alloc(sizeof(int32_t) * (size_t)B * cap_);
-    mt_ = (int32_t*)alloc(sizeof(int32_t) * (size_t)B * cap_);
-    md_ = (float*)alloc(sizeof(float) * (size_t)B * cap_);
-    mc_ = (int32_t*)alloc(sizeof(int32_t) * B);
+    const size_t S = (size_t)cfg.matchSets;
+    idx_ = (int32_t*)alloc(sizeof(int32_t) * S * B * cap_ * 2);
+    dist_ = (int32_t*)alloc(sizeof(int32_t) * S * B * cap_ * 2);
+    mq_ = (int32_t*)alloc(sizeof(int32_t) * S * B * cap_);
+    mt_ = (int32_t*)alloc(sizeof(int32_t) * S * B * cap_);
+    md_ = (float*)alloc(sizeof(float) * S * B * cap_);
+    mc_ = (int32_t*)alloc(sizeof(int32_t) * S * B);
 }
 
 MultiStreamRunner::~MultiStreamRunner()
@@ -67,15 +68,19 @@ void MultiStreamRunner::extract(int set, int slot)
           "mslam_orb_extract_batch_dev", ctx_);
 }
 
-void MultiStreamRunner::match(int slot_query, int slot_train, float ratio)
+void MultiStreamRunner::match(int slot_query, int slot_train, float ratio, int set)
 {
+    if (set < 0 || set >= cfg_.matchSets) throw std::runtime_error("MultiStreamRunner::match: no such match set");
+    const size_t o = (size_t)set * cfg_.streams * cap_;
     check(mslam_match_knn2_batch_dev(ctx_, desc_.at((size_t)slot_query), n_.at((size_t)slot_query), desc_.at((size_t)slot_train), n_.at((size_t)slot_train),
-                                     cap_, cfg_.streams, idx_, dist_, ratio, mq_, mt_, md_, mc_), "mslam_match_knn2_batch_dev", ctx_);
+                                     cap_, cfg_.streams, idx_ + 2 * o, dist_ + 2 * o, ratio, mq_ + o, mt_ + o, md_ + o, mc_ + (size_t)set * cfg_.streams),
+          "mslam_match_knn2_batch_dev", ctx_);
 }
 
 void MultiStreamRunner::setPnpProblems(int capP, int H, const double* X, const double* x, const int32_t* P, const double* K, const double* dist,
-                                       const int32_t* samples, const mslam_pnp_params& prm)
+                                       const int32_t* samples, const mslam_pnp_params& prm, const uint64_t* seeds)
 {
+    if (!samples && !seeds) throw std::runtime_error("MultiStreamRunner::setPnpProblems: neither sample tables nor seeds");
     const int B = cfg_.streams;
     check(mslam_sync(pnp_ctx_), "mslam_sync", pnp_ctx_);
     if (capP != capP_ || H != H_) {
@@ -87,13 +92,17 @@ void MultiStreamRunner::setPnpProblems(int capP, int H, const double* X, const d
         pP_ = (int32_t*)alloc(sizeof(int32_t) * B); pS_ = (int32_t*)alloc(sizeof(int32_t) * (size_t)B * H * 4);
         p_Rt_ = (double*)alloc(sizeof(double) * B * 12); p_counts_ = (int32_t*)alloc(sizeof(int32_t) * (size_t)B * H);
         p_best_ = (int32_t*)alloc(sizeof(int32_t) * B); p_ninl_ = (int32_t*)alloc(sizeof(int32_t) * B);
-        p_inl_ = (uint8_t*)alloc((size_t)B * capP);
+        p_inl_ = (uint8_t*)alloc((size_t)B * capP); pSeed_ = (uint64_t*)alloc(sizeof(uint64_t) * B);
         capP_ = capP; H_ = H;
     }
     auto up = [&](void* d, const void* s, size_t n) { check(mslam_memcpy_h2d(pnp_ctx_, d, s, n), "mslam_memcpy_h2d", pnp_ctx_); };
     up(pX_, X, sizeof(double) * (size_t)B * capP * 3); up(px_, x, sizeof(double) * (size_t)B * capP * 2);
     up(pK_, K, sizeof(double) * B * 9); up(pD_, dist, sizeof(double) * B * 8); up(pP_, P, sizeof(int32_t) * B);
-    up(pS_, samples, sizeof(int32_t) * (size_t)B * H * 4);
+    if (samples) up(pS_, samples, sizeof(int32_t) * (size_t)B * H * 4);
+    else {
+        up(pSeed_, seeds, sizeof(uint64_t) * B);
+        check(mslam_sample_tables_dev(pnp_ctx_, pP_, pSeed_, H, 4, B, pS_), "mslam_sample_tables_dev", pnp_ctx_);
+    }
     pnp_prm_ = prm;
 }
 
@@ -125,9 +134,16 @@ void MultiStreamRunner::downloadFeatures(int slot, int stream, int n, std::vecto
     if (desc) check(mslam_memcpy_d2h(ctx_, desc, desc_.at((size_t)slot) + (size_t)stream * cap_ * 32, (size_t)n * 32), "mslam_memcpy_d2h", ctx_);
 }
 
-void MultiStreamRunner::downloadMatches(std::vector<int32_t>& count, std::vector<int32_t>& query, std::vector<int32_t>& train, std::vector<float>& dist)
+void MultiStreamRunner::downloadKeypoints(int slot, std::vector<mslam_keypoint>& kps)
 {
-    const size_t B = (size_t)cfg_.streams, n = B * cap_;
+    kps.resize((size_t)cfg_.streams * cap_);
+    check(mslam_memcpy_d2h(ctx_, kps.data(), kps_.at((size_t)slot), sizeof(mslam_keypoint) * kps.size()), "mslam_memcpy_d2h", ctx_);
+}
+
+void MultiStreamRunner::downloadMatches(std::vector<int32_t>& count, std::vector<int32_t>& query, std::vector<int32_t>& train, std::vector<float>& dist, int nsets)
+{
+    if (nsets < 1 || nsets > cfg_.matchSets) throw std::runtime_error("MultiStreamRunner::downloadMatches: no such match set");
+    const size_t B = (size_t)cfg_.streams * (size_t)nsets, n = B * cap_;
     count.resize(B); query.resize(n); train.resize(n); dist.resize(n);
     check(mslam_memcpy_d2h_async(ctx_, query.data(), mq_, sizeof(int32_t) * n), "mslam_memcpy_d2h_async", ctx_);
     check(mslam_memcpy_d2h_async(ctx_, train.data(), mt_, sizeof(int32_t) * n), "mslam_memcpy_d2h_async", ctx_);

@@ -21,6 +21,7 @@ public:
         int capacitySlack = 1024;      // room for response ties (retainBest keeps every tie)
         int ring = 2;                  // feature slots kept per stream (current + previous ones)
         int frameSets = 2;             // device-resident frame buffers (ingest double-buffering / alternating sets)
+        int matchSets = 1;             // match result buffers: match(.., set) calls of one tick can be enqueued back to back and read with one download
         bool pnpOnSecondStream = true;
         Config() { mslam_orb_default_params(&orb); }
     };
@@ -39,22 +40,31 @@ public:
     void uploadFramesAsync(int set, const uint8_t* pinned_frames);     // enqueued on the extract stream
     // ---- stages (enqueue only; no host synchronisation)
     void extract(int set, int slot);                                   // frames[set] -> feature ring slot
-    void match(int slot_query, int slot_train, float ratio);           // kNN-2 + ratio test + ordered compaction
+    void match(int slot_query, int slot_train, float ratio, int set = 0); // kNN-2 + ratio test + ordered compaction, results into match set `set`
     // B PnP problems resident on the device: X (B x capP x 3), x (B x capP x 2), P (B), K (B x 9), dist (B x 8), samples (B x H x 4)
+    // samples == nullptr: the tables are drawn on the device from `seeds` (B values; mslam_sample_tables_dev == geom::sampleTable(P[b], H, 4, seeds[b]))
     void setPnpProblems(int capP, int H, const double* X, const double* x, const int32_t* P, const double* K, const double* dist,
-                        const int32_t* samples, const mslam_pnp_params& prm);
+                        const int32_t* samples, const mslam_pnp_params& prm, const uint64_t* seeds = nullptr);
     void pnp();
     void sync();
 
     // ---- results (synchronise the stream they come from)
     void downloadCounts(int slot, std::vector<int32_t>& n, std::vector<int32_t>* status = nullptr);
     void downloadFeatures(int slot, int stream, int n, std::vector<mslam_keypoint>& kps, uint8_t* desc /* n x 32 or null */);
-    void downloadMatches(std::vector<int32_t>& count, std::vector<int32_t>& query, std::vector<int32_t>& train, std::vector<float>& dist); // B x cap each
+    void downloadKeypoints(int slot, std::vector<mslam_keypoint>& kps /* B x cap, one copy for all streams */);
+    // the first `nsets` match sets: count (nsets x B), query / train / dist (nsets x B x cap)
+    void downloadMatches(std::vector<int32_t>& count, std::vector<int32_t>& query, std::vector<int32_t>& train, std::vector<float>& dist, int nsets = 1);
     void downloadKnn(int stream, int nq, std::vector<int32_t>& idx, std::vector<int32_t>& dist);
     void downloadPnp(std::vector<double>& Rt /*B x 12*/, std::vector<int32_t>& best, std::vector<int32_t>& ninl, std::vector<int32_t>* counts = nullptr /*B x H*/,
                      std::vector<uint8_t>* inliers = nullptr /*B x capP*/);
     // device views for callers that chain their own _dev calls
     const uint8_t* descDev(int slot) const { return desc_[slot]; }
+    const mslam_keypoint* kpsDev(int slot) const { return kps_[slot]; }
+    // match results, all sets contiguous: set s, stream b at (s * B + b) [* cap]
+    const int32_t* matchQueryDev() const { return mq_; }
+    const int32_t* matchTrainDev() const { return mt_; }
+    const float* matchDistDev() const { return md_; }
+    const int32_t* matchCountDev() const { return mc_; }
     const int32_t* countDev(int slot) const { return n_[slot]; }
     const int32_t* pnpCountsDev() const { return p_counts_; }
     int pnpHyps() const { return H_; }
@@ -71,6 +81,7 @@ private:
     int32_t *status_ = nullptr, *idx_ = nullptr, *dist_ = nullptr, *mq_ = nullptr, *mt_ = nullptr, *mc_ = nullptr;
     float* md_ = nullptr;
     double *pX_ = nullptr, *px_ = nullptr, *pK_ = nullptr, *pD_ = nullptr, *p_Rt_ = nullptr;
+    uint64_t* pSeed_ = nullptr;
     int32_t *pP_ = nullptr, *pS_ = nullptr, *p_counts_ = nullptr, *p_best_ = nullptr, *p_ninl_ = nullptr;
     uint8_t* p_inl_ = nullptr;
     mslam_pnp_params pnp_prm_{};

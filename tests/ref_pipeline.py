@@ -24,10 +24,20 @@ class Rng:
         return (self.next() >> 32) % n
 
 
+def splitmix64(z):
+    z &= M64
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & M64
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M64
+    return z ^ (z >> 31)
+
+
 def sample_table(n, H, k, seed):
-    rng = Rng(seed)
+    """geom::sampleTable / mslam_sample_tables_dev: row h has its own generator, Rng(splitmix64(seed + (h+1) * golden))."""
     out = np.zeros((H, k), np.int32)
+    if n < k:
+        return out
     for h in range(H):
+        rng = Rng(splitmix64(seed + (h + 1) * 0x9E3779B97F4A7C15))
         for i in range(k):
             while True:
                 v = rng.below(n)
@@ -56,7 +66,7 @@ def fundamental(ob, p1, p2, qi, ti, seed, H=2000):
     return r["F"], r["status"], a, b
 
 
-def run(ob, frames, K, nfeatures=500, seed=0x5EED, pnp_hyps=100, pnp_thr=8.0, dist=None):
+def run(ob, frames, K, nfeatures=500, seed=5, pnp_hyps=100, pnp_thr=8.0, dist=None):   # seed = CameraPoseEstimator::seed's default (Stages.h)
     """Returns per-frame dict(kps, desc, Rt, map_idx) and the map (positions, observers)."""
     p = ob.orb_default_params(nfeatures)
     dist = np.zeros(8) if dist is None else dist

@@ -2,6 +2,7 @@
 eigen-solver, 3x3 SVD, dense LDL^T, Rt <-> SE3Quat, SE3 exp, essential-matrix decomposition, pose concatenation as
 written in the reference, sample tables -- against numpy on random inputs (through the mslam_geometry_check hook)."""
 import os
+import sys
 import subprocess
 
 import numpy as np
@@ -122,6 +123,15 @@ def test_sample_tables_are_distinct_and_reproducible():
     assert all(len(set(r)) == 8 for r in T)
     (d,) = run(["table 8 5 8 3"])
     assert all(sorted(r) == list(range(8)) for r in d.reshape(5, 8).astype(int))
+    # the stated generator (row h: xorshift64* from splitmix64(seed + (h+1) * golden)), restated in tests/ref_pipeline.py;
+    # mslam_sample_tables_dev draws the same tables on the device (tests/test_ransac_gpu.py)
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import ref_pipeline
+    np.testing.assert_array_equal(T, ref_pipeline.sample_table(50, 200, 8, 77))
+    (e,) = run(["table 1500 64 4 24301"])
+    np.testing.assert_array_equal(e.reshape(64, 4).astype(int), ref_pipeline.sample_table(1500, 64, 4, 24301))
+    (z,) = run(["table 3 6 4 9"])
+    assert not z.any()                           # n < k: a zero table
 
 
 def test_util_computef_and_frame_id_table(tmp_path):

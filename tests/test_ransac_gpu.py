@@ -268,3 +268,49 @@ def test_hypothesis_sharding_over_ranks_equals_the_unsharded_run(ctx, oracle):
     assert g["best_h"] == full["best_h"] and g["n_inliers"] == full["n_inliers"]
     np.testing.assert_array_equal(g["inliers"], full["inliers"])
     np.testing.assert_array_equal(g["Rt"], full["Rt"])      # same kernels on the same sample: bit-identical
+
+
+def test_device_sample_tables_equal_the_stated_generator(ctx):
+    """mslam_sample_tables_dev vs the Python restatement of geom::sampleTable (tests/ref_pipeline.py): rows are
+    independent, so the device draws one row per thread and must give the same table bit for bit."""
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import ref_pipeline
+    n = np.array([500, 8, 9, 7, 0, 1524, 40], np.int32)
+    seeds = np.array([0x5EED, 1, 2, 3, 4, 2**63 + 12345, 0], np.uint64)
+    for k, H in ((8, 300), (4, 257), (1, 5)):
+        T = ctx.sample_tables(n, seeds, H, k)
+        assert T.shape == (n.size, H, k)
+        for b in range(n.size):
+            np.testing.assert_array_equal(T[b], ref_pipeline.sample_table(int(n[b]), H, k, int(seeds[b])), err_msg=f"table {b} k={k}")
+            if n[b] >= k:
+                assert T[b].min() >= 0 and T[b].max() < n[b]
+                assert all(len(set(r)) == k for r in T[b].tolist())
+    with pytest.raises(api.MslamError):
+        ctx.sample_tables(n, seeds, 10, 9)      # k > 8 is refused
+
+
+def test_gather_matches_dev_widens_the_matched_keypoints(ctx):
+    """mslam_gather_matches_dev: x1/x2 of computeFundamentalMatrix (src/CameraPoseEstimator.cpp:553-571) straight from the
+    resident keypoints and match lists; counts below min_count give M = 0."""
+    rng = np.random.default_rng(5)
+    B, cap = 5, 300
+    kdt = np.dtype([("x", "f4"), ("y", "f4"), ("size", "f4"), ("angle", "f4"), ("response", "f4"), ("octave", "i4")])
+    kq = np.zeros((B, cap), kdt); kt = np.zeros((B, cap), kdt)
+    for a in (kq, kt):
+        a["x"] = rng.uniform(0, 1920, a.shape).astype(np.float32); a["y"] = rng.uniform(0, 1080, a.shape).astype(np.float32)
+    count = np.array([300, 7, 8, 0, 123], np.int32)
+    q = rng.integers(0, cap, (B, cap)).astype(np.int32); t = rng.integers(0, cap, (B, cap)).astype(np.int32)
+    d = [api.DevBuf.from_array(ctx, a) for a in (kq, kt, q, t, count)]
+    x1 = api.DevBuf.from_array(ctx, np.full((B, cap, 2), -1.0)); x2 = api.DevBuf.from_array(ctx, np.full((B, cap, 2), -1.0))
+    M = api.DevBuf(ctx, 4 * B)
+    ctx.gather_matches_dev(d[0].ptr, d[1].ptr, cap, d[2].ptr, d[3].ptr, d[4].ptr, B, 8, x1.ptr, x2.ptr, M.ptr)
+    X1, X2 = x1.download(np.float64, (B, cap, 2)), x2.download(np.float64, (B, cap, 2))
+    np.testing.assert_array_equal(M.download(np.int32, (B,)), [300, 0, 8, 0, 123])
+    for b in range(B):
+        m = count[b]
+        np.testing.assert_array_equal(X1[b, :m, 0], kq["x"][b, q[b, :m]].astype(np.float64))
+        np.testing.assert_array_equal(X1[b, :m, 1], kq["y"][b, q[b, :m]].astype(np.float64))
+        np.testing.assert_array_equal(X2[b, :m, 0], kt["x"][b, t[b, :m]].astype(np.float64))
+        np.testing.assert_array_equal(X2[b, :m, 1], kt["y"][b, t[b, :m]].astype(np.float64))
+        assert (X1[b, m:] == -1.0).all() and (X2[b, m:] == -1.0).all()      # nothing written past the count
