@@ -374,15 +374,16 @@ class BaPlan:
 
 
 def _ctx_methods():
-    def fmat_ransac8(self, x1, x2, samples, params: FmatParams):
-        """R8/R9: eight-point F-matrix RANSAC over an explicit H x 8 sample table."""
+    def fmat_ransac8(self, x1, x2, samples, params: FmatParams, want_counts: bool = True):
+        """R8/R9: eight-point F-matrix RANSAC over an explicit H x 8 sample table.  want_counts=False leaves out the
+        per-hypothesis counts, which lets the library stop at the adaptive iteration bound (same winner, same F)."""
         x1 = np.ascontiguousarray(x1, np.float64); x2 = np.ascontiguousarray(x2, np.float64)
         samples = np.ascontiguousarray(samples, np.int32)
         M, H = x1.shape[0], samples.shape[0]
-        F = np.zeros(9); status = np.zeros(M, np.uint8); counts = np.zeros(H, np.int32)
+        F = np.zeros(9); status = np.zeros(M, np.uint8); counts = np.zeros(H, np.int32) if want_counts else None
         best, ninl = C.c_int(-1), C.c_int(0)
         rc = lib().mslam_fmat_ransac8(self._h, _p(x1, f64p), _p(x2, f64p), M, _p(samples, i32p), H, C.byref(params),
-                                      _p(F, f64p), _p(status, u8p), _p(counts, i32p), C.byref(best), C.byref(ninl))
+                                      _p(F, f64p), _p(status, u8p), _p(counts, i32p) if want_counts else None, C.byref(best), C.byref(ninl))
         if rc not in (OK, ERR_DEGENERATE):
             self._check(rc, "mslam_fmat_ransac8")
         return dict(rc=rc, F=F.reshape(3, 3), status=status, counts=counts, best_h=best.value, n_inliers=ninl.value)

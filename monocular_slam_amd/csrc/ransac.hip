@@ -305,6 +305,9 @@ struct FmatArgs {
     int32_t* counts;  // [B][H]
     int32_t* best;    // [B]
     double* F; uint8_t* status; int32_t* n_inliers;
+    // hypotheses [h_lo, h_hi) of this launch; state (optional): {niters, best, maxgood} per problem, the adaptive bound
+    // carried from one range to the next -- blocks past it have nothing to contribute and return
+    int h_lo, h_hi; int32_t* state;
 };
 
 __global__ __launch_bounds__(256)
@@ -324,7 +327,10 @@ void fmat_prepare_k(FmatArgs a)
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) { if (tid < o) s_max[tid] = fmax(s_max[tid], s_max[tid + o]); __syncthreads(); }
     const double maxt = s_max[0];
-    if (tid == 0) a.maxt[b] = maxt;
+    if (tid == 0) {
+        a.maxt[b] = maxt;
+        if (a.state) { a.state[3 * b] = M >= 8 ? a.H : 0; a.state[3 * b + 1] = -1; a.state[3 * b + 2] = 0; }
+    }
     double* pts = a.pts + (size_t)b * a.capM * 4;
     for (int i = tid; i < M; i += 256) {
         double u1 = x1[2 * i], v1 = x1[2 * i + 1], u2 = x2[2 * i], v2 = x2[2 * i + 1];
@@ -340,8 +346,9 @@ __global__ __launch_bounds__(64)
 void fmat_solve_k(FmatArgs a)
 {
     const int b = blockIdx.y;
-    const int h = blockIdx.x * 64 + threadIdx.x;
-    if (h >= a.H) return;
+    const int h = a.h_lo + blockIdx.x * 64 + threadIdx.x;
+    if (a.state && a.h_lo + (int)blockIdx.x * 64 >= a.state[3 * b]) return; // past the adaptive bound (block-uniform)
+    if (h >= a.h_hi) return;
     const int M = a.M[b];
     const double maxt = a.maxt[b];
     const double* x1 = a.x1 + (size_t)b * a.capM * 2;
@@ -413,8 +420,9 @@ constexpr int FM_PT = 8;
 __global__ __launch_bounds__(SCORE_THREADS)
 void fmat_score_k(FmatArgs a)
 {
-    const int b = blockIdx.y, h0 = blockIdx.x * FM_HPB, tid = threadIdx.x, lane = tid & 63;
-    const int nh = min(FM_HPB, a.H - h0);
+    const int b = blockIdx.y, h0 = a.h_lo + blockIdx.x * FM_HPB, tid = threadIdx.x, lane = tid & 63;
+    if (a.state && h0 >= a.state[3 * b]) return; // past the adaptive bound (block-uniform)
+    const int nh = min(FM_HPB, a.h_hi - h0);
     const int M = a.M[b];
     __shared__ double s_F[FM_HPB][9];
     __shared__ int s_cnt[FM_HPB];
@@ -499,16 +507,19 @@ __device__ int ransac_update_iters(double p, double ep, int model_points, int ma
 // the adaptive iteration bound.  Chunks of 64 counts are skipped unless one beats the best.
 __global__ __launch_bounds__(64)
 void ransac_select_k(const int32_t* __restrict__ counts, const int32_t* __restrict__ npts, int H, int sample_size,
-                     double confidence, int32_t* __restrict__ best_out, int32_t* __restrict__ best_cnt_out)
+                     double confidence, int32_t* __restrict__ best_out, int32_t* __restrict__ best_cnt_out,
+                     int h_lo, int h_hi, int32_t* __restrict__ state)
 {
+    // state (optional): the scan continues over [h_lo, h_hi) from where the previous range left {niters, best, maxgood}
     const int b = blockIdx.x, lane = threadIdx.x;
     const int32_t* c = counts + (size_t)b * H;
     const int n_points = npts[b];
     const bool adaptive = confidence > 0. && confidence < 1.;
     int niters = H, best = -1, maxgood = 0;
-    for (int i0 = 0; i0 < niters; i0 += 64) {
+    if (state) { niters = state[3 * b]; best = state[3 * b + 1]; maxgood = state[3 * b + 2]; }
+    for (int i0 = h_lo; i0 < niters && i0 < h_hi; i0 += 64) {
         const int i = i0 + lane;
-        const int v = i < H ? c[i] : -1;
+        const int v = i < h_hi ? c[i] : -1;
         int floor_ = maxgood > sample_size - 1 ? maxgood : sample_size - 1;
         unsigned long long bal = __ballot(i < niters && v > floor_);
         while (bal) { // record breakers in index order
@@ -525,7 +536,11 @@ void ransac_select_k(const int32_t* __restrict__ counts, const int32_t* __restri
             }
         }
     }
-    if (lane == 0) { best_out[b] = best; if (best_cnt_out) best_cnt_out[b] = maxgood; }
+    if (lane == 0) {
+        best_out[b] = best;
+        if (best_cnt_out) best_cnt_out[b] = maxgood;
+        if (state) { state[3 * b] = niters; state[3 * b + 1] = best; state[3 * b + 2] = maxgood; }
+    }
 }
 
 // block-wide (NT threads) sum of NV doubles per thread in a fixed order (deterministic, no atomics): values are
@@ -1419,7 +1434,7 @@ int mslam_fmat_ransac8_batch_dev(mslam_ctx* ctx, const double* x1, const double*
     auto reserve = [&](size_t n) { bytes = align_up(bytes, 256); size_t o = bytes; bytes += n; return o; };
     const size_t o_pts = reserve(sizeof(double) * 4 * (size_t)B * capM), o_maxt = reserve(sizeof(double) * B),
                  o_mod = reserve(sizeof(double) * 9 * (size_t)B * H), o_mods = reserve(sizeof(double) * 9 * (size_t)B * H),
-                 o_cnt = reserve(sizeof(int32_t) * (size_t)B * H);
+                 o_cnt = reserve(sizeof(int32_t) * (size_t)B * H), o_state = reserve(sizeof(int32_t) * 3 * (size_t)B);
     void* scr = nullptr;
     MSLAM_TRY(ctx_scratch(ctx, bytes, &scr));
     char* base = (char*)scr;
@@ -1432,10 +1447,23 @@ int mslam_fmat_ransac8_batch_dev(mslam_ctx* ctx, const double* x1, const double*
     a.counts = inlier_counts ? inlier_counts : (int32_t*)(base + o_cnt);
     a.best = best_h; a.F = F; a.status = status; a.n_inliers = n_inliers;
     hipStream_t st = ctx->stream;
+    // With an adaptive bound (0 < confidence < 1, the reference's 0.85) only the hypotheses before the point where the
+    // sequential RANSAC loop would stop can win, typically a few dozen of H.  Unless the caller asks for every count, the
+    // hypotheses go out in growing ranges and each range's select pass carries {niters, best, maxgood} to the next: blocks
+    // past the bound return at once.  The winner is the one the single full pass finds (the scan is the same scan).
+    const bool ranged = !inlier_counts && prm->confidence > 0. && prm->confidence < 1. && H > 64;
+    a.state = ranged ? (int32_t*)(base + o_state) : nullptr;
+    a.h_lo = 0; a.h_hi = H;
     LAUNCH(ctx, K_FMAT_PREPARE, fmat_prepare_k, dim3(B), dim3(256), 0, a);
-    LAUNCH(ctx, K_FMAT_SOLVE, fmat_solve_k, dim3((H + 63) / 64, B), dim3(64), 0, a);
-    LAUNCH(ctx, K_FMAT_SCORE, fmat_score_k, dim3((H + FM_HPB - 1) / FM_HPB, B), dim3(SCORE_THREADS), 0, a);
-    LAUNCH(ctx, K_RANSAC_SELECT, ransac_select_k, dim3(B), dim3(64), 0, a.counts, M, H, 8, prm->confidence, best_h, (int32_t*)nullptr);
+    static const int bounds[] = { 64, 256, 1024 };
+    for (int r = 0, lo = 0; lo < H; r++) {
+        const int hi = (ranged && r < 3 && bounds[r] < H) ? bounds[r] : H;
+        a.h_lo = lo; a.h_hi = hi;
+        LAUNCH(ctx, K_FMAT_SOLVE, fmat_solve_k, dim3((hi - lo + 63) / 64, B), dim3(64), 0, a);
+        LAUNCH(ctx, K_FMAT_SCORE, fmat_score_k, dim3((hi - lo + FM_HPB - 1) / FM_HPB, B), dim3(SCORE_THREADS), 0, a);
+        LAUNCH(ctx, K_RANSAC_SELECT, ransac_select_k, dim3(B), dim3(64), 0, a.counts, M, H, 8, prm->confidence, best_h, (int32_t*)nullptr, lo, hi, a.state);
+        lo = hi;
+    }
     LAUNCH(ctx, K_FMAT_FINALIZE, fmat_finalize_k, dim3(B), dim3(256), 0, a);
     HIP_TRY(ctx, hipGetLastError());
     return MSLAM_OK;
@@ -1507,7 +1535,7 @@ int mslam_pnp_ransac_batch_dev(mslam_ctx* ctx, const double* X, const double* x,
     LAUNCH(ctx, K_PNP_PREPARE, pnp_prepare_k, dim3((capP + 255) / 256, B), dim3(256), 0, a);
     LAUNCH(ctx, K_PNP_SOLVE, pnp_solve_k, dim3((H + 63) / 64, B), dim3(64), 0, a);
     LAUNCH(ctx, K_PNP_SCORE, pnp_score_k, dim3((H + PNP_HPB - 1) / PNP_HPB, B), dim3(SCORE_THREADS), 0, a);
-    LAUNCH(ctx, K_RANSAC_SELECT, ransac_select_k, dim3(B), dim3(64), 0, a.counts, P, H, 4, prm->confidence, best_h, a.best_cnt);
+    LAUNCH(ctx, K_RANSAC_SELECT, ransac_select_k, dim3(B), dim3(64), 0, a.counts, P, H, 4, prm->confidence, best_h, a.best_cnt, 0, H, (int32_t*)nullptr);
     LAUNCH(ctx, K_PNP_FINALIZE, pnp_finalize_k, dim3(B), dim3(FIN_THREADS), 0, a);
     HIP_TRY(ctx, hipGetLastError());
     return MSLAM_OK;

@@ -225,6 +225,12 @@ void BatchedPipeline::matchFilterMany(int slotQ, const std::vector<int>& slotsT,
     mslam_ctx* ctx = runner_->ctx();
     auto up256 = [](size_t v) { return (v + 255) & ~(size_t)255; };
     const size_t nl = (size_t)N * cap;
+    if (!scratch_sized_) {   // size the buffers for the full back-traverse depth once: no reallocation while the ring fills up
+        const size_t Nmax = (size_t)(ring_ - 1) * B, nlmax = Nmax * cap;
+        (void)scratch(0, 2 * up256(sizeof(double) * nlmax * 2) + up256(sizeof(int32_t) * Nmax * H * 8) + up256(sizeof(int32_t) * Nmax) + up256(sizeof(uint64_t) * Nmax));
+        (void)scratch(1, up256(sizeof(double) * 9 * Nmax) + up256(nlmax) + up256(sizeof(int32_t) * 2 * Nmax));
+        scratch_sized_ = true;
+    }
     // device scratch: x1, x2, tables, M, seeds | F, status, best, ninl
     const size_t o_x2 = up256(sizeof(double) * nl * 2), o_S = 2 * o_x2, o_M = o_S + up256(sizeof(int32_t) * (size_t)N * H * 8), o_sd = o_M + up256(sizeof(int32_t) * N);
     uint8_t* in = (uint8_t*)scratch(0, o_sd + up256(sizeof(uint64_t) * N));
@@ -237,10 +243,12 @@ void BatchedPipeline::matchFilterMany(int slotQ, const std::vector<int>& slotsT,
     const size_t h_q = up256(sizeof(uint64_t) * N), h_t = h_q + up256(4 * nl), h_d = h_t + up256(4 * nl), h_c = h_d + up256(4 * nl), h_st = h_c + up256(4 * (size_t)N),
                  h_F = h_st + up256(nl), h_b = h_F + up256(sizeof(double) * 9 * N), h_end = h_b + up256(4 * (size_t)N);
     if (h_end > arena_bytes_) {
+        const size_t Nmax = (size_t)(ring_ - 1) * B;
+        const size_t want = std::max(h_end, (h_end / (size_t)N + 1) * Nmax);
         if (arena_) chk(mslam_host_free(ctx, arena_), "mslam_host_free");
         arena_ = nullptr; arena_bytes_ = 0;
-        chk(mslam_host_alloc(ctx, &arena_, h_end + h_end / 4), "mslam_host_alloc");
-        arena_bytes_ = h_end + h_end / 4;
+        chk(mslam_host_alloc(ctx, &arena_, want + want / 8), "mslam_host_alloc");
+        arena_bytes_ = want + want / 8;
     }
     uint8_t* hp = (uint8_t*)arena_;
     {
@@ -451,60 +459,66 @@ void BatchedPipeline::posePnp(int frameIdx)
         if (best[(size_t)b] >= 0 && ninl[(size_t)b] >= cpe_.pnp.min_inliers) dms_[(size_t)b]->frames[(size_t)frameIdx].Rt = matFrom(&Rt[(size_t)b * 12], 3, 4);
         else lastStatus[(size_t)b] = MSLAM_ERR_DEGENERATE;
     }
-    // ---- triangulate the matches not yet tied to a map point, against each previous frame (:488-512): per back frame one
-    // batched call over the streams (the association state of a stream advances from one back frame to the next, so the
-    // back frames stay sequential)
+    // ---- triangulate the matches not yet tied to a map point, against each previous frame (:488-512).  Which pairs get a new
+    // point depends on the association state only (it advances from one back frame to the next), not on the 3D positions:
+    // each stream registers its new points first (position pending), then ONE batched triangulation over all
+    // (stream, back frame) groups fills the positions in.
     PhaseTimer ptTri(phaseMs[PH_TRIANGULATE]);
-    for (int i = frameIdx - 1; i >= 0 && i >= frameIdx - cpe_.numBackTraverse; i--) {
-        const size_t mi = (size_t)(frameIdx - 1 - i);
-        std::vector<double> gx1, gx2, gRt1, gRt2, gK1, gK2;
-        std::vector<int32_t> ofs(1, 0), gstream;
-        std::vector<std::vector<std::pair<int, int>>> gpairs;
-        for (int b = 0; b < B; b++) {
-            if (mi >= ps[(size_t)b].cachedMatches.size()) continue;   // this stream left the loop earlier (:456)
-            DataManager& data = *dms_[(size_t)b];
-            Frame& cur = data.frames[(size_t)frameIdx];
+    struct Group { int back; size_t firstPoint, n; };
+    struct NewPoints { std::vector<Group> groups; std::vector<double> x1, x2; };
+    std::vector<NewPoints> np((size_t)B);
+    parallelStreams(B, [&](int b) {
+        DataManager& data = *dms_[(size_t)b];
+        Frame& cur = data.frames[(size_t)frameIdx];
+        Features& curF = cur.features;
+        NewPoints& out = np[(size_t)b];
+        for (size_t mi = 0; mi < ps[(size_t)b].cachedMatches.size(); mi++) {   // fewer than nb entries: the stream left the loop earlier (:456)
+            const int i = frameIdx - 1 - (int)mi;
             Frame& pre = data.frames[(size_t)i];
-            Features& curF = cur.features;
             Features& preF = pre.features;
-            std::vector<std::pair<int, int>> pairs;
-            const size_t x0 = gx1.size();
+            Group g{ i, data.mapPoints.size(), 0 };
             for (const cv::DMatch& m : ps[(size_t)b].cachedMatches[mi]) {
                 const int cf = m.queryIdx, pf = m.trainIdx;
-                // both ends unassociated; a feature associated earlier in THIS loop is skipped like in the reference,
-                // where the test runs after each registerNewMapPoint
-                if (preF.mapPointsIndices[(size_t)pf] == -1 && curF.mapPointsIndices[(size_t)cf] == -1) {
-                    bool dup = false;
-                    for (const auto& pr : pairs) dup |= (pr.first == pf || pr.second == cf);
-                    if (dup) continue;
-                    pairs.push_back({ pf, cf });
-                    gx1.push_back(preF.positions[(size_t)pf].x); gx1.push_back(preF.positions[(size_t)pf].y);
-                    gx2.push_back(curF.positions[(size_t)cf].x); gx2.push_back(curF.positions[(size_t)cf].y);
+                if (preF.mapPointsIndices[(size_t)pf] == -1 && curF.mapPointsIndices[(size_t)cf] == -1) {   // both ends unassociated (:493)
+                    registerNewMapPoint(data, Point3d(0, 0, 0), pre, pf, cur, cf);
+                    out.x1.push_back(preF.positions[(size_t)pf].x); out.x1.push_back(preF.positions[(size_t)pf].y);
+                    out.x2.push_back(curF.positions[(size_t)cf].x); out.x2.push_back(curF.positions[(size_t)cf].y);
+                    g.n++;
                 }
             }
-            if (pairs.empty()) { gx1.resize(x0); gx2.resize(x0); continue; }
+            if (g.n) out.groups.push_back(g);
+        }
+    });
+    std::vector<double> gx1, gx2, gRt1, gRt2, gK1, gK2;
+    std::vector<int32_t> ofs(1, 0);
+    for (int b = 0; b < B; b++) {
+        const NewPoints& o = np[(size_t)b];
+        if (o.groups.empty()) continue;
+        DataManager& data = *dms_[(size_t)b];
+        Frame& cur = data.frames[(size_t)frameIdx];
+        gx1.insert(gx1.end(), o.x1.begin(), o.x1.end()); gx2.insert(gx2.end(), o.x2.begin(), o.x2.end());
+        for (const Group& g : o.groups) {
+            Frame& pre = data.frames[(size_t)g.back];
             double m12[12], k9[9];
             matTo(pre.Rt, m12, 12); gRt1.insert(gRt1.end(), m12, m12 + 12);
             matTo(cur.Rt, m12, 12); gRt2.insert(gRt2.end(), m12, m12 + 12);
             matTo(pre.K, k9, 9); gK1.insert(gK1.end(), k9, k9 + 9);
             matTo(cur.K, k9, 9); gK2.insert(gK2.end(), k9, k9 + 9);
-            ofs.push_back(ofs.back() + (int32_t)pairs.size());
-            gstream.push_back(b);
-            gpairs.push_back(std::move(pairs));
-        }
-        const int G = (int)gstream.size();
-        if (G == 0) continue;
-        std::vector<double> gX((size_t)ofs.back() * 3);
-        chk(mslam_triangulate_batch(runner_->ctx(), gx1.data(), gx2.data(), ofs.data(), G, gRt1.data(), gRt2.data(), gK1.data(), gK2.data(), gX.data(), nullptr, nullptr),
-            "mslam_triangulate_batch");
-        for (int g = 0; g < G; g++) {
-            DataManager& data = *dms_[(size_t)gstream[(size_t)g]];
-            const double* Xn = gX.data() + (size_t)ofs[(size_t)g] * 3;
-            for (size_t k = 0; k < gpairs[(size_t)g].size(); k++)
-                registerNewMapPoint(data, Point3d(Xn[3 * k], Xn[3 * k + 1], Xn[3 * k + 2]), data.frames[(size_t)i], gpairs[(size_t)g][k].first,
-                                    data.frames[(size_t)frameIdx], gpairs[(size_t)g][k].second);
+            ofs.push_back(ofs.back() + (int32_t)g.n);
         }
     }
+    const int G = (int)ofs.size() - 1;
+    if (G == 0) return;
+    std::vector<double> gX((size_t)ofs.back() * 3);
+    chk(mslam_triangulate_batch(runner_->ctx(), gx1.data(), gx2.data(), ofs.data(), G, gRt1.data(), gRt2.data(), gK1.data(), gK2.data(), gX.data(), nullptr, nullptr),
+        "mslam_triangulate_batch");
+    size_t g0 = 0;
+    for (int b = 0; b < B; b++)
+        for (const Group& g : np[(size_t)b].groups) {
+            const double* Xn = gX.data() + (size_t)ofs[g0++] * 3;
+            DataManager& data = *dms_[(size_t)b];
+            for (size_t k = 0; k < g.n; k++) data.mapPoints[g.firstPoint + k].worldPosition = Point3d(Xn[3 * k], Xn[3 * k + 1], Xn[3 * k + 2]);
+        }
 }
 
 void BatchedPipeline::process(int frameIdx)

@@ -63,6 +63,7 @@ private:
     int device_, ring_, w_ = 0, h_ = 0, ch_ = 0;
     std::unique_ptr<MultiStreamRunner> runner_;
     void* pinned_ = nullptr; size_t pinned_bytes_ = 0;
+    bool scratch_sized_ = false;
     void* arena_ = nullptr; size_t arena_bytes_ = 0;   // pinned up/download buffer of matchFilterMany
     void* dscratch_[4] = { nullptr, nullptr, nullptr, nullptr }; size_t dscratch_bytes_[4] = { 0, 0, 0, 0 };
 };

@@ -314,3 +314,23 @@ def test_gather_matches_dev_widens_the_matched_keypoints(ctx):
         np.testing.assert_array_equal(X2[b, :m, 0], kt["x"][b, t[b, :m]].astype(np.float64))
         np.testing.assert_array_equal(X2[b, :m, 1], kt["y"][b, t[b, :m]].astype(np.float64))
         assert (X1[b, m:] == -1.0).all() and (X2[b, m:] == -1.0).all()      # nothing written past the count
+
+
+@pytest.mark.parametrize("outlier_frac,H", [(0.25, 2000), (0.6, 2000), (0.8, 1500), (0.25, 65), (0.95, 300)])
+def test_fmat_ranged_prefix_gives_the_full_pass_winner(ctx, outlier_frac, H):
+    """Without the per-hypothesis counts the library evaluates the hypotheses in growing ranges and stops at the adaptive
+    iteration bound (confidence 0.85, src/CameraPoseEstimator.cpp:585); winner, F, mask and inlier count must be the ones of
+    the single full pass.  The outlier fractions put the stopping point in the first range, in later ranges and nowhere."""
+    for seed in (21, 22, 23):
+        pr = synth.two_view_problem(700, seed, outlier_frac=outlier_frac)
+        S = synth.sample_table(700, H, 8, seed)
+        p = api.default_fmat_params()
+        full = ctx.fmat_ransac8(pr["x1"], pr["x2"], S, p)
+        part = ctx.fmat_ransac8(pr["x1"], pr["x2"], S, p, want_counts=False)
+        assert part["rc"] == full["rc"] and part["best_h"] == full["best_h"] and part["n_inliers"] == full["n_inliers"]
+        np.testing.assert_array_equal(part["status"], full["status"])
+        np.testing.assert_array_equal(part["F"], full["F"])
+    few = ctx.fmat_ransac8(pr["x1"][:8], pr["x2"][:8], synth.sample_table(8, 100, 8, 1), p, want_counts=False)   # exactly 8 pairs
+    ref = ctx.fmat_ransac8(pr["x1"][:8], pr["x2"][:8], synth.sample_table(8, 100, 8, 1), p)
+    assert few["best_h"] == ref["best_h"] and few["rc"] == ref["rc"]
+    np.testing.assert_array_equal(few["F"], ref["F"])
