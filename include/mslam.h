@@ -72,6 +72,9 @@ int mslam_memcpy_d2h(mslam_ctx* ctx, void* dst_host, const void* src_dev, uint64
 int mslam_memcpy_h2d_async(mslam_ctx* ctx, void* dst_dev, const void* src_host, uint64_t bytes);
 int mslam_memcpy_d2h_async(mslam_ctx* ctx, void* dst_host, const void* src_dev, uint64_t bytes);
 int mslam_memcpy_d2d_async(mslam_ctx* ctx, void* dst_dev, const void* src_dev, uint64_t bytes);
+/* `rows` rows of `width` bytes from a pitched device array into a pitched host array (the used left part of capacity-padded
+ * per-stream tables, e.g. the first max-count columns of the B x cap match lists) */
+int mslam_memcpy_d2h_2d_async(mslam_ctx* ctx, void* dst_host, uint64_t dst_pitch, const void* src_dev, uint64_t src_pitch, uint64_t width, uint64_t rows);
 int mslam_host_alloc(mslam_ctx* ctx, void** hptr, uint64_t bytes);   /* pinned (page-locked) host memory */
 int mslam_host_free(mslam_ctx* ctx, void* hptr);
 /* make this context's stream wait for an event recorded (mslam_event_record) on another context of the same device */

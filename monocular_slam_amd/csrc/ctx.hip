@@ -184,6 +184,15 @@ int mslam_memcpy_d2h_async(mslam_ctx* ctx, void* dst, const void* src, uint64_t 
     return MSLAM_OK;
 }
 
+int mslam_memcpy_d2h_2d_async(mslam_ctx* ctx, void* dst, uint64_t dst_pitch, const void* src, uint64_t src_pitch, uint64_t width, uint64_t rows)
+{
+    if (!ctx || width > dst_pitch || width > src_pitch || (width && rows && (!dst || !src))) return MSLAM_ERR_INVALID;
+    if (!width || !rows) return MSLAM_OK;
+    MSLAM_TRY(ctx_set_device(ctx));
+    HIP_TRY(ctx, hipMemcpy2DAsync(dst, dst_pitch, src, src_pitch, width, rows, hipMemcpyDeviceToHost, ctx->stream));
+    return MSLAM_OK;
+}
+
 int mslam_memcpy_d2d_async(mslam_ctx* ctx, void* dst, const void* src, uint64_t bytes)
 {
     if (!ctx || (bytes && (!dst || !src))) return MSLAM_ERR_INVALID;

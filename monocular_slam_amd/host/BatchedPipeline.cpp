@@ -137,6 +137,22 @@ void* BatchedPipeline::scratch(int slot, size_t bytes)
     return dscratch_[slot];
 }
 
+// frames[frameIdx] of every stream, rows packed, into the pinned half frameIdx & 1
+void BatchedPipeline::stageFrames(int frameIdx)
+{
+    const int B = streams();
+    const size_t row = (size_t)w_ * ch_, fb = row * h_;
+    uint8_t* dst = (uint8_t*)pinned_ + (size_t)(frameIdx & 1) * pinned_bytes_;
+    for (int b = 0; b < B; b++) {
+        const cv::Mat& img = dms_[(size_t)b]->frames.at((size_t)frameIdx).frameBuffer;
+        if (img.cols != w_ || img.rows != h_ || img.channels() != ch_) throw std::runtime_error("BatchedPipeline: all streams must share one frame geometry");
+    }
+    parallelStreams(B, [&](int b) {
+        const cv::Mat& img = dms_[(size_t)b]->frames[(size_t)frameIdx].frameBuffer;
+        for (int y = 0; y < h_; y++) std::memcpy(dst + (size_t)b * fb + (size_t)y * row, img.data + img.step * (size_t)y, row);
+    });
+}
+
 // ---- FeatureExtractor::process for all streams (src/FeatureExtractor.cpp:13-31)
 void BatchedPipeline::extractAll(int frameIdx)
 {
@@ -149,37 +165,46 @@ void BatchedPipeline::extractAll(int frameIdx)
         cfg.capacitySlack = fe_.capacitySlack; cfg.ring = ring_; cfg.frameSets = 2; cfg.matchSets = ring_ - 1; cfg.pnpOnSecondStream = false;
         runner_.reset(new MultiStreamRunner(cfg));
         pinned_bytes_ = (size_t)w_ * ch_ * h_ * B;
-        chk(mslam_host_alloc(runner_->ctx(), &pinned_, pinned_bytes_), "mslam_host_alloc");
-    }
-    const size_t row = (size_t)w_ * ch_, fb = row * h_;
-    {
-        PhaseTimer pt(phaseMs[PH_STAGE_FRAMES]);
-        for (int b = 0; b < B; b++) {
-            const cv::Mat& img = dms_[(size_t)b]->frames.at((size_t)frameIdx).frameBuffer;
-            if (img.cols != w_ || img.rows != h_ || img.channels() != ch_) throw std::runtime_error("BatchedPipeline: all streams must share one frame geometry");
-        }
-        parallelStreams(B, [&](int b) {
-            const cv::Mat& img = dms_[(size_t)b]->frames[(size_t)frameIdx].frameBuffer;
-            for (int y = 0; y < h_; y++) std::memcpy((uint8_t*)pinned_ + (size_t)b * fb + (size_t)y * row, img.data + img.step * (size_t)y, row);
-        });
+        chk(mslam_host_alloc(runner_->ctx(), &pinned_, 2 * pinned_bytes_), "mslam_host_alloc");
     }
     const int set = frameIdx & 1, slot = slotOf(frameIdx);
+    uint8_t* half[2] = { (uint8_t*)pinned_, (uint8_t*)pinned_ + pinned_bytes_ };
     std::vector<int32_t> n, st;
+    if (prefetched_ != frameIdx) {
+        { PhaseTimer pt(phaseMs[PH_STAGE_FRAMES]); stageFrames(frameIdx); }
+        PhaseTimer pt(phaseMs[PH_EXTRACT]);
+        runner_->uploadFramesAsync(set, half[set]);
+    }
     {
         PhaseTimer pt(phaseMs[PH_EXTRACT]);
-        runner_->uploadFramesAsync(set, (const uint8_t*)pinned_);
-        runner_->extract(set, slot);
-        runner_->downloadCounts(slot, n, &st);   // syncs: the pinned buffer may be refilled from here on
+        runner_->extract(set, slot);   // waits on the device for a prefetched set
+    }
+    bool next = prefetchNextFrame;
+    for (int b = 0; b < B && next; b++) {
+        const std::vector<Frame>& fr = dms_[(size_t)b]->frames;
+        next = (size_t)frameIdx + 1 < fr.size() && fr[(size_t)frameIdx + 1].frameBuffer.cols == w_ && fr[(size_t)frameIdx + 1].frameBuffer.rows == h_ &&
+               fr[(size_t)frameIdx + 1].frameBuffer.channels() == ch_;
+    }
+    if (next) {   // host staging and the copy both overlap the extraction just enqueued
+        { PhaseTimer pt(phaseMs[PH_STAGE_FRAMES]); stageFrames(frameIdx + 1); }
+        runner_->uploadFramesPrefetch(set ^ 1, half[set ^ 1]);
+        prefetched_ = frameIdx + 1;
+    }
+    {
+        PhaseTimer pt(phaseMs[PH_EXTRACT]);
+        runner_->downloadCounts(slot, n, &st);   // syncs the extract stream
     }
     PhaseTimer pt(phaseMs[PH_FEATURES_DOWN]);
     const int cap = runner_->cap();
+    if (slotFeatures_.size() != (size_t)ring_) slotFeatures_.assign((size_t)ring_, 0);
+    slotFeatures_[(size_t)slot] = 0;
+    for (int b = 0; b < B; b++) slotFeatures_[(size_t)slot] = std::max(slotFeatures_[(size_t)slot], n[(size_t)b]);
     for (int b = 0; b < B; b++) chk(st[(size_t)b], "mslam_orb_extract_batch_dev (per-frame status)");
-    std::vector<mslam_keypoint> all;
-    runner_->downloadKeypoints(slot, all);   // one copy for the B streams
+    const mslam_keypoint* all = runner_->downloadKeypointsPinned(slot);   // one copy for the B streams
     parallelStreams(B, [&](int b) {
         Frame& frame = dms_[(size_t)b]->frames[(size_t)frameIdx];
         const int nb = n[(size_t)b];
-        const mslam_keypoint* kps = all.data() + (size_t)b * cap;
+        const mslam_keypoint* kps = all + (size_t)b * cap;
         frame.features.positions.reserve((size_t)nb); frame.features.scales.reserve((size_t)nb);
         for (int i = 0; i < nb; i++) {
             frame.features.positions.push_back(Point2d(cv::Point2f(kps[i].x, kps[i].y)));   // Point2f -> Point2d widening
@@ -265,11 +290,13 @@ void BatchedPipeline::matchFilterMany(int slotQ, const std::vector<int>& slotsT,
     }
     PhaseTimer pt(phaseMs[PH_FMAT]);
     chk(mslam_fmat_ransac8_batch_dev(ctx, dx1, dx2, dM, cap, dS, H, N, &cpe_.fmat, dF, dst, nullptr, dbest, dninl), "mslam_fmat_ransac8_batch_dev");
-    chk(mslam_memcpy_d2h_async(ctx, hp + h_q, runner_->matchQueryDev(), 4 * nl), "mslam_memcpy_d2h_async");
-    chk(mslam_memcpy_d2h_async(ctx, hp + h_t, runner_->matchTrainDev(), 4 * nl), "mslam_memcpy_d2h_async");
-    chk(mslam_memcpy_d2h_async(ctx, hp + h_d, runner_->matchDistDev(), 4 * nl), "mslam_memcpy_d2h_async");
+    // a match list holds at most as many entries as the query frame has features: only those columns of the cap-wide tables travel
+    const size_t used = (size_t)std::min(cap, std::max(slotFeatures_[(size_t)slotQ], 1));
+    chk(mslam_memcpy_d2h_2d_async(ctx, hp + h_q, 4 * (size_t)cap, runner_->matchQueryDev(), 4 * (size_t)cap, 4 * used, (size_t)N), "mslam_memcpy_d2h_2d_async");
+    chk(mslam_memcpy_d2h_2d_async(ctx, hp + h_t, 4 * (size_t)cap, runner_->matchTrainDev(), 4 * (size_t)cap, 4 * used, (size_t)N), "mslam_memcpy_d2h_2d_async");
+    chk(mslam_memcpy_d2h_2d_async(ctx, hp + h_d, 4 * (size_t)cap, runner_->matchDistDev(), 4 * (size_t)cap, 4 * used, (size_t)N), "mslam_memcpy_d2h_2d_async");
     chk(mslam_memcpy_d2h_async(ctx, hp + h_c, runner_->matchCountDev(), 4 * (size_t)N), "mslam_memcpy_d2h_async");
-    chk(mslam_memcpy_d2h_async(ctx, hp + h_st, dst, nl), "mslam_memcpy_d2h_async");
+    chk(mslam_memcpy_d2h_2d_async(ctx, hp + h_st, (size_t)cap, dst, (size_t)cap, used, (size_t)N), "mslam_memcpy_d2h_2d_async");
     chk(mslam_memcpy_d2h_async(ctx, hp + h_F, dF, sizeof(double) * 9 * N), "mslam_memcpy_d2h_async");
     chk(mslam_memcpy_d2h_async(ctx, hp + h_b, dbest, 4 * (size_t)N), "mslam_memcpy_d2h_async");
     chk(mslam_sync(ctx), "mslam_sync");   // the only synchronisation of the stage

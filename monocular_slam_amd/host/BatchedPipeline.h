@@ -33,6 +33,10 @@ public:
     std::vector<int> lastStatus;       // per stream: MSLAM_OK or the status that made the pose stage keep the previous pose
     MultiStreamRunner* runner() { return runner_.get(); }
     bool eagerDescriptors = false;     // true: fill Frame.features.descriptors for every frame right after extraction
+    // true: while frame i is being extracted, frame i + 1 (if every stream already holds it, as after FrameLoader::load --
+    // src/main.cpp:35-37) is staged and copied to the device on a copy stream.  A frame buffer that is replaced between
+    // process(i) and process(i + 1) would be missed: switch this off for such a caller.
+    bool prefetchNextFrame = true;
     // host wall time per phase, accumulated over the ticks (milliseconds; device work counts where the host waits for it)
     enum Phase { PH_STAGE_FRAMES, PH_EXTRACT, PH_FEATURES_DOWN, PH_MATCH, PH_FMAT_PREP, PH_FMAT, PH_ASSOCIATE, PH_PNP_PREP, PH_PNP, PH_TRIANGULATE, PH_COUNT };
     double phaseMs[PH_COUNT] = { 0 };
@@ -62,8 +66,11 @@ private:
     CameraPoseEstimator cpe_;
     int device_, ring_, w_ = 0, h_ = 0, ch_ = 0;
     std::unique_ptr<MultiStreamRunner> runner_;
-    void* pinned_ = nullptr; size_t pinned_bytes_ = 0;
+    void* pinned_ = nullptr; size_t pinned_bytes_ = 0;   // two staging buffers of B frames (frame i uses half i & 1)
+    int prefetched_ = -1;                                 // frame index already on its way to the device
+    void stageFrames(int frameIdx);
     bool scratch_sized_ = false;
+    std::vector<int> slotFeatures_;    // per ring slot: the largest feature count over the streams
     void* arena_ = nullptr; size_t arena_bytes_ = 0;   // pinned up/download buffer of matchFilterMany
     void* dscratch_[4] = { nullptr, nullptr, nullptr, nullptr }; size_t dscratch_bytes_[4] = { 0, 0, 0, 0 };
 };

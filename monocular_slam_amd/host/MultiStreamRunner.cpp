@@ -44,6 +44,12 @@ MultiStreamRunner::~MultiStreamRunner()
 {
     if (ctx_) (void)mslam_sync(ctx_);
     if (pnp_ctx_ && pnp_ctx_ != ctx_) (void)mslam_sync(pnp_ctx_);
+    if (copy_ctx_) {
+        (void)mslam_sync(copy_ctx_);
+        for (void* e : copy_ev_) if (e) (void)mslam_event_destroy(copy_ctx_, e);
+        mslam_destroy(copy_ctx_);
+    }
+    if (kps_pinned_) (void)mslam_host_free(ctx_, kps_pinned_);
     for (void* p : owned_pnp_) (void)mslam_dev_free(pnp_ctx_, p);
     for (void* p : owned_) (void)mslam_dev_free(ctx_, p);
     if (pnp_ctx_ && pnp_ctx_ != ctx_) mslam_destroy(pnp_ctx_);
@@ -60,8 +66,25 @@ void MultiStreamRunner::uploadFramesAsync(int set, const uint8_t* pinned_frames)
     check(mslam_memcpy_h2d_async(ctx_, frames_.at((size_t)set), pinned_frames, (size_t)cfg_.w * cfg_.channels * cfg_.h * cfg_.streams), "mslam_memcpy_h2d_async", ctx_);
 }
 
+void MultiStreamRunner::uploadFramesPrefetch(int set, const uint8_t* pinned_frames)
+{
+    if (!copy_ctx_) {
+        check(mslam_create(&copy_ctx_, cfg_.device, cfg_.w, cfg_.h, 4096, 1), "mslam_create", nullptr);   // a stream; its kernels' buffers are never touched
+        copy_ev_.assign((size_t)cfg_.frameSets, nullptr);
+        copy_pending_.assign((size_t)cfg_.frameSets, 0);
+        for (void*& e : copy_ev_) check(mslam_event_create(copy_ctx_, &e), "mslam_event_create", copy_ctx_);
+    }
+    check(mslam_memcpy_h2d_async(copy_ctx_, frames_.at((size_t)set), pinned_frames, (size_t)cfg_.w * cfg_.channels * cfg_.h * cfg_.streams), "mslam_memcpy_h2d_async", copy_ctx_);
+    check(mslam_event_record(copy_ctx_, copy_ev_[(size_t)set]), "mslam_event_record", copy_ctx_);
+    copy_pending_[(size_t)set] = 1;
+}
+
 void MultiStreamRunner::extract(int set, int slot)
 {
+    if (copy_ctx_ && copy_pending_.at((size_t)set)) {   // the frames of this set arrive on the copy stream
+        check(mslam_stream_wait_event(ctx_, copy_ev_[(size_t)set]), "mslam_stream_wait_event", ctx_);
+        copy_pending_[(size_t)set] = 0;
+    }
     const int stride = cfg_.w * cfg_.channels;
     check(mslam_orb_extract_batch_dev(ctx_, frames_.at((size_t)set), cfg_.streams, cfg_.w, cfg_.h, stride, (int64_t)stride * cfg_.h, cfg_.channels,
                                       &cfg_.orb, kps_.at((size_t)slot), desc_.at((size_t)slot), cap_, n_.at((size_t)slot), status_),
@@ -117,6 +140,7 @@ void MultiStreamRunner::sync()
 {
     check(mslam_sync(ctx_), "mslam_sync", ctx_);
     if (pnp_ctx_ != ctx_) check(mslam_sync(pnp_ctx_), "mslam_sync", pnp_ctx_);
+    if (copy_ctx_) check(mslam_sync(copy_ctx_), "mslam_sync", copy_ctx_);
 }
 
 void MultiStreamRunner::downloadCounts(int slot, std::vector<int32_t>& n, std::vector<int32_t>* status)
@@ -138,6 +162,15 @@ void MultiStreamRunner::downloadKeypoints(int slot, std::vector<mslam_keypoint>&
 {
     kps.resize((size_t)cfg_.streams * cap_);
     check(mslam_memcpy_d2h(ctx_, kps.data(), kps_.at((size_t)slot), sizeof(mslam_keypoint) * kps.size()), "mslam_memcpy_d2h", ctx_);
+}
+
+const mslam_keypoint* MultiStreamRunner::downloadKeypointsPinned(int slot)
+{
+    const size_t bytes = sizeof(mslam_keypoint) * (size_t)cfg_.streams * cap_;
+    if (!kps_pinned_) check(mslam_host_alloc(ctx_, &kps_pinned_, bytes), "mslam_host_alloc", ctx_);
+    check(mslam_memcpy_d2h_async(ctx_, kps_pinned_, kps_.at((size_t)slot), bytes), "mslam_memcpy_d2h_async", ctx_);
+    check(mslam_sync(ctx_), "mslam_sync", ctx_);
+    return (const mslam_keypoint*)kps_pinned_;
 }
 
 void MultiStreamRunner::downloadMatches(std::vector<int32_t>& count, std::vector<int32_t>& query, std::vector<int32_t>& train, std::vector<float>& dist, int nsets)

@@ -38,6 +38,9 @@ public:
     // ---- frames: B images of h x stride bytes, contiguous; `set` selects the resident buffer
     void uploadFrames(int set, const uint8_t* host_frames);            // synchronous
     void uploadFramesAsync(int set, const uint8_t* pinned_frames);     // enqueued on the extract stream
+    // enqueued on a copy stream of its own (created on first use): overlaps the kernels running on the extract stream; the
+    // next extract(set, ..) waits for it on the device (event), the host does not
+    void uploadFramesPrefetch(int set, const uint8_t* pinned_frames);
     // ---- stages (enqueue only; no host synchronisation)
     void extract(int set, int slot);                                   // frames[set] -> feature ring slot
     void match(int slot_query, int slot_train, float ratio, int set = 0); // kNN-2 + ratio test + ordered compaction, results into match set `set`
@@ -52,6 +55,8 @@ public:
     void downloadCounts(int slot, std::vector<int32_t>& n, std::vector<int32_t>* status = nullptr);
     void downloadFeatures(int slot, int stream, int n, std::vector<mslam_keypoint>& kps, uint8_t* desc /* n x 32 or null */);
     void downloadKeypoints(int slot, std::vector<mslam_keypoint>& kps /* B x cap, one copy for all streams */);
+    // the same through a pinned buffer owned by the runner (valid until the next call): B x cap keypoints
+    const mslam_keypoint* downloadKeypointsPinned(int slot);
     // the first `nsets` match sets: count (nsets x B), query / train / dist (nsets x B x cap)
     void downloadMatches(std::vector<int32_t>& count, std::vector<int32_t>& query, std::vector<int32_t>& train, std::vector<float>& dist, int nsets = 1);
     void downloadKnn(int stream, int nq, std::vector<int32_t>& idx, std::vector<int32_t>& dist);
@@ -73,7 +78,9 @@ private:
     void check(int status, const char* what, mslam_ctx* c) const;
     Config cfg_;
     int cap_ = 0, capP_ = 0, H_ = 0;
-    mslam_ctx *ctx_ = nullptr, *pnp_ctx_ = nullptr;
+    mslam_ctx *ctx_ = nullptr, *pnp_ctx_ = nullptr, *copy_ctx_ = nullptr;
+    std::vector<void*> copy_ev_;        // per frame set: recorded behind the prefetch copy
+    std::vector<char> copy_pending_;
     std::vector<uint8_t*> frames_;
     std::vector<mslam_keypoint*> kps_;
     std::vector<uint8_t*> desc_;
@@ -86,4 +93,5 @@ private:
     uint8_t* p_inl_ = nullptr;
     mslam_pnp_params pnp_prm_{};
     std::vector<void*> owned_, owned_pnp_;
+    void* kps_pinned_ = nullptr;
 };

@@ -2,6 +2,7 @@
 // what pipeline_demo gives for each of them alone.  Output: per stream "stream s", then the pipeline_demo lines
 // ("frame i nfeat r00 .. r23", "mappoints M", "id x y z nobs").
 //   batched_demo out.txt in0.bin in1.bin ... [--nfeatures N] [--no-dist] [--pnp-hyps H] [--pnp-thr T] [--check-descriptors]
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstring>
@@ -81,7 +82,12 @@ int main(int argc, char** argv)
             for (size_t i = 2; i < tick_ms.size(); i++) { tail += tick_ms[i]; cnt++; }
             std::printf("], \"phase_ms_ticks_2_on\": {");
             for (int p = 0; p < BatchedPipeline::PH_COUNT; p++) std::printf("%s\"%s\": %.2f", p ? ", " : "", BatchedPipeline::phaseName(p), slam.phaseMs[p]);
-            std::printf("}, \"tracking_frames_per_s\": %.1f}\n", cnt ? 1e3 * dms.size() * cnt / tail : 0.0);
+            // steady state: the median tick once the feature ring is full (the first ticks also grow buffers and create streams)
+            std::vector<double> steady(tick_ms.begin() + std::min<size_t>(tick_ms.size(), 6), tick_ms.end());
+            std::sort(steady.begin(), steady.end());
+            const double med = steady.empty() ? 0.0 : steady[steady.size() / 2];
+            std::printf("}, \"tracking_frames_per_s\": %.1f, \"steady_tick_ms_median\": %.3f, \"steady_tracking_frames_per_s\": %.1f}\n",
+                        cnt ? 1e3 * dms.size() * cnt / tail : 0.0, med, med > 0 ? 1e3 * dms.size() / med : 0.0);
         }
         FILE* out = std::fopen(argv[1], "w");
         if (!out) { std::fprintf(stderr, "cannot write %s\n", argv[1]); return 2; }
