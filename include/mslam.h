@@ -253,7 +253,7 @@ int mslam_triangulate(mslam_ctx* ctx, const double* x1, const double* x2, int n,
 
 /* ---- device-side preparation of batched RANSAC inputs (what the stage classes otherwise assemble on the host) ----------
  * RANSAC in the reference draws its samples inside OpenCV (cv::findFundamentalMat / cv::solvePnPRansac,
- * src/CameraPoseEstimator.cpp:585, :472); here the sample tables are explicit inputs, and this is the stated generator
+ * src/CameraPoseEstimator.cpp:563, :472); here the sample tables are explicit inputs, and this is the stated generator
  * the stages use for them (monocular_slam_amd/host/Geometry.h geom::sampleTable, restated in tests/ref_pipeline.py):
  * table b = H rows of k distinct indices in [0, n[b]); row h is drawn by xorshift64* started from
  * splitmix64(seeds[b] + (h + 1) * 0x9E3779B97F4A7C15) (a zero state is replaced by that constant), each index
@@ -261,7 +261,7 @@ int mslam_triangulate(mslam_ctx* ctx, const double* x1, const double* x2, int n,
  * n, seeds: device arrays of B; tables: device, B x H x k.  n[b] < k gives a zero table.  1 <= k <= 8. */
 int mslam_sample_tables_dev(mslam_ctx* ctx, const int32_t* n, const uint64_t* seeds, int H, int k, int B, int32_t* tables);
 /* Matched pixel coordinates for mslam_fmat_ransac8_batch_dev from device-resident keypoints and match lists
- * (the gather of computeFundamentalMatrix, src/CameraPoseEstimator.cpp:553-571): for i < count[b]
+ * (the gather of computeFundamentalMatrix, src/CameraPoseEstimator.cpp:554-560): for i < count[b]
  *   x1[b][i] = (double) kps_q[b][query[b][i]].(x, y),   x2[b][i] = (double) kps_t[b][train[b][i]].(x, y)
  * (float -> double widening, as Point2f -> Point2d in the reference); kps_*: B x cap keypoints, query/train: B x cap,
  * x1/x2: B x cap x 2.  M_out[b] = count[b] if count[b] >= min_count else 0 (a problem the RANSAC kernels skip). */

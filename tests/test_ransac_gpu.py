@@ -291,7 +291,7 @@ def test_device_sample_tables_equal_the_stated_generator(ctx):
 
 
 def test_gather_matches_dev_widens_the_matched_keypoints(ctx):
-    """mslam_gather_matches_dev: x1/x2 of computeFundamentalMatrix (src/CameraPoseEstimator.cpp:553-571) straight from the
+    """mslam_gather_matches_dev: x1/x2 of computeFundamentalMatrix (src/CameraPoseEstimator.cpp:554-560) straight from the
     resident keypoints and match lists; counts below min_count give M = 0."""
     rng = np.random.default_rng(5)
     B, cap = 5, 300
@@ -319,7 +319,7 @@ def test_gather_matches_dev_widens_the_matched_keypoints(ctx):
 @pytest.mark.parametrize("outlier_frac,H", [(0.25, 2000), (0.6, 2000), (0.8, 1500), (0.25, 65), (0.95, 300)])
 def test_fmat_ranged_prefix_gives_the_full_pass_winner(ctx, outlier_frac, H):
     """Without the per-hypothesis counts the library evaluates the hypotheses in growing ranges and stops at the adaptive
-    iteration bound (confidence 0.85, src/CameraPoseEstimator.cpp:585); winner, F, mask and inlier count must be the ones of
+    iteration bound (confidence 0.85, src/CameraPoseEstimator.cpp:563); winner, F, mask and inlier count must be the ones of
     the single full pass.  The outlier fractions put the stopping point in the first range, in later ranges and nowhere."""
     for seed in (21, 22, 23):
         pr = synth.two_view_problem(700, seed, outlier_frac=outlier_frac)
