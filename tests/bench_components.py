@@ -101,6 +101,14 @@ def main():
     ofp = ob.fmat_default_params(); ofp.confidence = 0.0
     tc = cpu_time(lambda: ob.fmat_ransac8(tvs[0]["x1"], tvs[0]["x2"], S8, ofp))
     out["F eight-point RANSAC 2000x4096"] = dict(unit="problems/s", gpu=B / t, cpu=1 / tc, alg_bytes=32 * M + 32 * Hh + 72 + M + 4 * Hh)
+    # as the stages call it (src/CameraPoseEstimator.cpp:563): confidence 0.85, no per-hypothesis counts -> the library stops at the
+    # adaptive iteration bound (growing hypothesis ranges), like the sequential loop it stands in for
+    fpa = api.default_fmat_params()
+    t = gpu_time(ctx, lambda: ctx.fmat_ransac8_batch_dev(fb["x1"].ptr, fb["x2"].ptr, fb["M"].ptr, M, fb["S"].ptr, Hh, B, fpa, fb["F"].ptr,
+                                                         fb["st"].ptr, 0, fb["best"].ptr, fb["ninl"].ptr), tag='fmat_adaptive')
+    ofa = ob.fmat_default_params()
+    tca = cpu_time(lambda: ob.fmat_ransac8(tvs[0]["x1"], tvs[0]["x2"], S8, ofa))
+    out["F eight-point RANSAC 2000x4096, confidence 0.85 without counts (GPU stops at the adaptive bound; the oracle scores every hypothesis, then selects)"] = dict(unit="problems/s", gpu=B / t, cpu=1 / tca, alg_bytes=32 * M + 72 + M)
     # ---- C3 BA build
     pr = synth.ba_problem(10, 5000, 4004)
     plan = api.BaPlan(ctx, pr)
