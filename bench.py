@@ -44,7 +44,7 @@ ALG_BYTES = {
 }
 KERNEL_UNIT = {  # which per-frame unit a kernel's launch is priced against
     "bgr2gray_k": "extract", "resize_k": "extract", "pyramid2_k": "extract", "fast_nms_k": "extract", "select_k": "extract",
-    "describe_k": "extract", "hamming_knn2_partial": "match", "knn2_finalize": "match",
+    "describe_k": "extract", "hamming_knn2_partial": "match", "expand_pm1_k": "match", "hamming_mfma_k": "match", "knn2_finalize": "match",
     "pnp_prepare_k": "pnp", "pnp_solve_k": "pnp", "pnp_score_k": "pnp", "ransac_select_k": "pnp", "pnp_finalize_k": "pnp",
 }
 # f64 flops per (hypothesis, point) pair of pnp_score_k's sign test (3 rows x (3 fma) + e = A^2 + B^2 - z^2: DESIGN.md 4)

@@ -13,7 +13,16 @@
 // Kernel 2 (knn2_finalize): one workgroup per frame merges the per-chunk top-2 in chunk
 //   order, writes idx/dist, applies the float ratio test and compacts the survivors in
 //   query order with a ballot/prefix scan (deterministic, no atomics).
-// No MFMA: there is no dense contraction here, only xor/popcount/min.
+// MFMA form (default; MSLAM_MATCH_MFMA=0 selects the kernel above): with every descriptor bit b stored as the int8 value
+//   2b - 1, the dot product of two descriptors is (#equal bits - #different bits) = 256 - 2 * Hamming, so the 2000 x 2000
+//   distance table of a frame pair is an int8 Gram matrix and v_mfma_i32_32x32x32_i8 produces it exactly.  The tracking
+//   path as a whole is bound by VALU issue: this moves the xor/popcount work (16 of the 19 VALU
+//   instructions per pair and lane) onto the otherwise idle matrix pipe and leaves the top-2 bookkeeping on the VALU.
+//   expand_pm1_k writes the +-1 bytes in MFMA operand order (tile of 32 descriptors x k-step of 32 bits = 64 lanes x 16 B),
+//   so every operand load is one lane-linear 1 KiB read; hamming_mfma_k keeps 64 query columns per wavefront in registers
+//   (B operands), stages the train tiles through LDS (double-buffered, shared by the workgroup's two wavefronts) and folds
+//   each 32 x 32 tile into per-lane (best, second) keys.  The query side is stored negated and the accumulator starts at
+//   256, so a tile element IS 256 - dot = 2 * Hamming and a key is one v_lshl_add: (element << 16) + row.
 #include "common.h"
 
 namespace {
@@ -83,16 +92,147 @@ void hamming_knn2_partial(const uint8_t* __restrict__ q, const int32_t* __restri
     }
 }
 
+// ---- MFMA form ------------------------------------------------------------------------------------------------------
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+constexpr int MF_THREADS = 128;          // two wavefronts
+constexpr int MF_QPW = 64;               // query columns per wavefront (two 32-wide B blocks)
+
+// E[b][tile][s][lane] (16 bytes): lane = half * 32 + r holds bits [32 s + 16 half, +16) of descriptor 32 tile + r as +-1
+// bytes (zero bytes for rows past n: their dot products are never used).
+__global__ __launch_bounds__(256)
+void expand_pm1_k(const uint8_t* __restrict__ q, const int32_t* __restrict__ nq_arr, const uint8_t* __restrict__ t, const int32_t* __restrict__ nt_arr,
+                  int cap, int tiles_cap, int B, uint4* __restrict__ Eq, uint4* __restrict__ Et)
+{
+    // blockIdx.z < B: query side of frame blockIdx.z, stored negated; otherwise the train side of frame blockIdx.z - B
+    const bool train = (int)blockIdx.z >= B;
+    const int b = train ? blockIdx.z - B : blockIdx.z, s = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    const int n = train ? nt_arr[b] : nq_arr[b];
+    if (i >= ((n + 31) & ~31)) return;
+    const uint32_t flip = train ? 0xFFFFFFFFu : 0x01010101u;   // bit -> 0x01 / 0xFF (+1 / -1), or the negated pair
+    uint32_t w = 0;
+    const bool live = i < n;
+    if (live) w = reinterpret_cast<const uint32_t*>((train ? t : q) + ((size_t)b * cap + i) * 32)[s];
+    uint4* dst = (train ? Et : Eq) + (((size_t)b * tiles_cap + (i >> 5)) * 8 + s) * 64 + (i & 31);
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+        uint32_t o[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint32_t x = (w >> (16 * half + 4 * j)) & 0xFu;
+            const uint32_t m = (x * 0x00204081u) & 0x01010101u;          // bit j of the nibble -> bit 0 of byte j
+            o[j] = live ? (((m << 8) - (m << 1)) ^ flip) : 0u;            // m * 0xFE per byte, then the flip
+        }
+        dst[half * 32] = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+template <bool MASK>
+__device__ __forceinline__ void fold_tile(const v16i& acc, const int (&c)[16], int limit, uint32_t& best, uint32_t& second)
+{
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        uint32_t key = ((uint32_t)acc[i] << 16) + (uint32_t)c[i];   // 2 * Hamming << 16 | row
+        if (MASK) key = c[i] < limit ? key : KEY_NONE;
+        top2_update(best, second, key);
+    }
+}
+
+__global__ __launch_bounds__(MF_THREADS, 2)
+void hamming_mfma_k(const uint4* __restrict__ Eq, const int32_t* __restrict__ nq_arr, const uint4* __restrict__ Et,
+                    const int32_t* __restrict__ nt_arr, int cap, int tiles_cap, int nsplit, uint2* __restrict__ part)
+{
+    // blockIdx.y = which share of the train tiles this workgroup scans: more wavefronts per SIMD, so that one wavefront's
+    // top-2 bookkeeping (VALU) runs under another's MFMAs; knn2_finalize merges the nsplit partial keys per query
+    const int b = blockIdx.z, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nq = nq_arr[b], nt = nt_arr[b];
+    const int q0 = (blockIdx.x * 2 + wave) * MF_QPW;               // first query column of this wavefront
+    if (blockIdx.x * 2 * MF_QPW >= nq) return;                       // workgroup-uniform
+    __shared__ uint4 s_tile[2][8 * 64];                              // two train tiles of 8 KiB
+    const int nTall = (nt + 31) >> 5, per = (nTall + nsplit - 1) / nsplit;
+    const int t_lo = min((int)blockIdx.y * per, nTall), nT = min(t_lo + per, nTall) - t_lo;   // tiles [t_lo, t_lo + nT)
+    const uint4* et = Et + ((size_t)b * tiles_cap + t_lo) * 512;
+    // B operands: this wavefront's two query blocks, 8 k-steps each (columns past nq hold zero bytes or stale tiles; never written out)
+    v4i bq[2][8];
+    {
+        const uint4* eq = Eq + (size_t)b * tiles_cap * 512;
+        const int qt = q0 >> 5;
+#pragma unroll
+        for (int blk = 0; blk < 2; blk++) {
+            const int t = min(qt + blk, tiles_cap - 1);
+#pragma unroll
+            for (int s = 0; s < 8; s++) {
+                const uint4 v = eq[((size_t)t * 8 + s) * 64 + lane];
+                bq[blk][s] = v4i{ (int)v.x, (int)v.y, (int)v.z, (int)v.w };
+            }
+        }
+    }
+    // row (train index within the tile) of accumulator element i of this lane: 8 (i / 4) + 4 (lane / 32) + i % 4
+    int c[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) c[i] = 32 * t_lo + 8 * (i >> 2) + 4 * (lane >> 5) + (i & 3);
+    const int limit = nt;
+    v16i c256;
+#pragma unroll
+    for (int i = 0; i < 16; i++) c256[i] = 256;
+    uint32_t best[2] = { KEY_NONE, KEY_NONE }, second[2] = { KEY_NONE, KEY_NONE };
+    if (nT > 0) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) s_tile[0][(wave * 4 + j) * 64 + lane] = et[(size_t)(wave * 4 + j) * 64 + lane];
+    }
+    __syncthreads();
+    for (int t = 0; t < nT; t++) {
+        const bool more = t + 1 < nT;
+        // next tile: global -> registers now, registers -> the other LDS buffer after this tile's arithmetic (no branch around
+        // either: the last iteration re-reads its own tile into the buffer nobody looks at again)
+        const uint4* nx = et + ((size_t)(more ? t + 1 : t) * 8 + wave * 4) * 64 + lane;
+        const uint4 p0 = nx[0], p1 = nx[64], p2 = nx[128], p3 = nx[192];
+        const uint4* tile = s_tile[t & 1];
+        v16i acc0 = c256, acc1 = c256;   // 256 + (train . -query) = 2 * Hamming
+#pragma unroll
+        for (int s = 0; s < 8; s++) {
+            const uint4 v = tile[s * 64 + lane];
+            const v4i a = v4i{ (int)v.x, (int)v.y, (int)v.z, (int)v.w };
+            acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[0][s], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[1][s], acc1, 0, 0, 0);
+        }
+        if (more) {
+            fold_tile<false>(acc0, c, limit, best[0], second[0]);
+            fold_tile<false>(acc1, c, limit, best[1], second[1]);
+        } else {   // the last tile may hold rows past nt
+            fold_tile<true>(acc0, c, limit, best[0], second[0]);
+            fold_tile<true>(acc1, c, limit, best[1], second[1]);
+        }
+        uint4* nb = s_tile[(t + 1) & 1] + wave * 4 * 64 + lane;
+        nb[0] = p0; nb[64] = p1; nb[128] = p2; nb[192] = p3;
+#pragma unroll
+        for (int i = 0; i < 16; i++) c[i] += 32;
+        __syncthreads();
+    }
+    // lanes l and l ^ 32 hold the same query column (different rows): merge, then the lower half writes
+#pragma unroll
+    for (int blk = 0; blk < 2; blk++) {
+        const uint32_t ob = (uint32_t)__shfl_xor((int)best[blk], 32), os = (uint32_t)__shfl_xor((int)second[blk], 32);
+        top2_update(best[blk], second[blk], ob);
+        top2_update(best[blk], second[blk], os);
+        const int qi = q0 + blk * 32 + (lane & 31);
+        // keys carry 2 * Hamming: back to (Hamming << 16 | row), the form knn2_finalize reads
+        const uint32_t kb = best[blk] == KEY_NONE ? KEY_NONE : ((best[blk] >> 17) << 16) | (best[blk] & 0xFFFFu);
+        const uint32_t ks = second[blk] == KEY_NONE ? KEY_NONE : ((second[blk] >> 17) << 16) | (second[blk] & 0xFFFFu);
+        if (lane < 32 && qi < nq) part[((size_t)b * nsplit + blockIdx.y) * cap + qi] = make_uint2(kb, ks);
+    }
+}
+
 __global__ __launch_bounds__(256)
 void knn2_finalize(const uint2* __restrict__ part, const int32_t* __restrict__ nq_arr,
                    const int32_t* __restrict__ nt_arr, int cap, int nchunks,
                    int32_t* __restrict__ idx, int32_t* __restrict__ dist, float ratio,
                    int32_t* __restrict__ m_query, int32_t* __restrict__ m_train, float* __restrict__ m_dist,
-                   int32_t* __restrict__ m_count)
+                   int32_t* __restrict__ m_count, int all_chunks)
 {
     const int b = blockIdx.x;
     const int nq = nq_arr[b], nt = nt_arr[b];
-    const int used = (nt + TC - 1) / TC;
+    const int used = all_chunks ? nchunks : (nt + TC - 1) / TC;   // all_chunks: every chunk holds keys (KEY_NONE if it saw no rows): hamming_mfma_k
     __shared__ int wave_cnt[4];
     __shared__ int base_s;
     if (threadIdx.x == 0) base_s = 0;
@@ -151,14 +291,30 @@ int mslam_match_knn2_batch_dev(mslam_ctx* ctx, const uint8_t* q, const int32_t* 
     if (ratio > 0.f && (!m_query || !m_train || !m_dist || !m_count)) return MSLAM_ERR_INVALID;
     if (((uintptr_t)q | (uintptr_t)t) & 15) return MSLAM_ERR_INVALID; // 16-B aligned rows
     MSLAM_TRY(ctx_set_device(ctx));
-    const int nchunks = (cap + TC - 1) / TC;
+    static const int use_mfma = [] { const char* e = getenv("MSLAM_MATCH_MFMA"); return e ? atoi(e) : 1; }();
     void* scr = nullptr;
+    if (use_mfma) {
+        const int tiles_cap = (cap + 31) / 32;
+        static const int nsplit = [] { const char* e = getenv("MSLAM_MATCH_SPLIT"); const int v = e ? atoi(e) : 4; return v < 1 ? 1 : (v > 16 ? 16 : v); }();
+        const size_t e_bytes = align_up((size_t)B * tiles_cap * 8192, 256), p_bytes = align_up(sizeof(uint2) * (size_t)B * nsplit * cap, 256);
+        MSLAM_TRY(ctx_scratch(ctx, 2 * e_bytes + p_bytes, &scr));
+        uint4* Eq = (uint4*)scr; uint4* Et = (uint4*)((char*)scr + e_bytes);
+        uint2* part = (uint2*)((char*)scr + 2 * e_bytes);
+        LAUNCH(ctx, K_MATCH_EXPAND, expand_pm1_k, dim3((tiles_cap * 32 + 255) / 256, 8, 2 * B), dim3(256), 0, q, nq, t, nt, cap, tiles_cap, B, Eq, Et);
+        LAUNCH(ctx, K_MATCH_MFMA, hamming_mfma_k, dim3((cap + 2 * MF_QPW - 1) / (2 * MF_QPW), nsplit, B), dim3(MF_THREADS), 0, (const uint4*)Eq, nq, (const uint4*)Et, nt,
+               cap, tiles_cap, nsplit, part);
+        LAUNCH(ctx, K_MATCH_FINALIZE, knn2_finalize, dim3(B), dim3(256), 0, (const uint2*)part, nq, nt, cap, nsplit, idx, dist,
+               ratio, m_query, m_train, m_dist, ratio > 0.f ? m_count : (int32_t*)nullptr, 1);
+        HIP_TRY(ctx, hipGetLastError());
+        return MSLAM_OK;
+    }
+    const int nchunks = (cap + TC - 1) / TC;
     MSLAM_TRY(ctx_scratch(ctx, sizeof(uint2) * (size_t)B * nchunks * cap, &scr));
     uint2* part = (uint2*)scr;
     dim3 grid((cap + MATCH_THREADS * QPL - 1) / (MATCH_THREADS * QPL), nchunks, B);
     LAUNCH(ctx, K_MATCH_PARTIAL, hamming_knn2_partial, grid, dim3(MATCH_THREADS), 0, q, nq, t, nt, cap, nchunks, part);
-    LAUNCH(ctx, K_MATCH_FINALIZE, knn2_finalize, dim3(B), dim3(256), 0, part, nq, nt, cap, nchunks, idx, dist,
-                       ratio, m_query, m_train, m_dist, ratio > 0.f ? m_count : (int32_t*)nullptr);
+    LAUNCH(ctx, K_MATCH_FINALIZE, knn2_finalize, dim3(B), dim3(256), 0, (const uint2*)part, nq, nt, cap, nchunks, idx, dist,
+                       ratio, m_query, m_train, m_dist, ratio > 0.f ? m_count : (int32_t*)nullptr, 0);
     HIP_TRY(ctx, hipGetLastError());
     return MSLAM_OK;
 }

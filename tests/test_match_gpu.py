@@ -37,6 +37,19 @@ def test_ragged_sizes(ctx, oracle, nq, nt):
     _check(ctx, oracle, q, t)
 
 
+@pytest.mark.parametrize("nq,nt", [(31, 33), (32, 32), (33, 31), (127, 129), (128, 128), (129, 96), (2000, 95), (95, 2000), (1999, 2017), (65, 4095)])
+def test_sizes_around_the_mfma_tiles(ctx, oracle, nq, nt):
+    """The matcher works on tiles of 32 train rows x 64 query columns per wavefront and cuts the train tiles into shares
+    (hamming_mfma_k): sizes one off the tile, wavefront and workgroup boundaries, shares with no tile at all (nt = 95 with 4
+    shares of 1 tile), and rows of all-zero / all-one bits (dot products at both ends of the int8 range)."""
+    rng = np.random.default_rng(nq * 104729 + nt)
+    q = rng.integers(0, 256, size=(nq, 32), dtype=np.uint8)
+    t = rng.integers(0, 256, size=(nt, 32), dtype=np.uint8)
+    q[0] = 0; q[-1] = 255
+    t[nt // 2] = 0; t[-1] = 255; t[0] = q[nq // 2]          # distances 0 and 256 occur
+    _check(ctx, oracle, q, t)
+
+
 def test_ties_go_to_lower_train_index(ctx, oracle):
     """Collisions: duplicated train rows and all-equal distances must rank by train index."""
     rng = np.random.default_rng(5)
