@@ -99,3 +99,15 @@ struct Bump {
 };
 
 void orb_plan_destroy(mslam_ctx* ctx);
+
+#ifdef __HIPCC__
+// XCD-aware work-item order: the dispatcher deals consecutive workgroups round-robin over the 8 XCDs (each with its own
+// L2), so workgroups orig, orig + 8, ... share an L2.  This bijection gives every XCD one CONTIGUOUS range of the
+// logical tile order, so tiles that share image rows / cache lines (tile halos, neighbouring keypoint patches) are
+// fetched into one L2 instead of up to eight.  Speed only: any placement computes the same result.
+__device__ __forceinline__ unsigned xcd_contiguous(unsigned orig, unsigned nwg)
+{
+    const unsigned q = nwg >> 3, r = nwg & 7u, xcd = orig & 7u;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+}
+#endif

@@ -144,13 +144,18 @@ void hamming_mfma_k(const uint4* __restrict__ Eq, const int32_t* __restrict__ nq
 {
     // blockIdx.y = which share of the train tiles this workgroup scans: more wavefronts per SIMD, so that one wavefront's
     // top-2 bookkeeping (VALU) runs under another's MFMAs; knn2_finalize merges the nsplit partial keys per query
-    const int b = blockIdx.z, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // XCD-contiguous work order with the frame slowest: the workgroups that share a frame's train tiles run on one XCD, so
+    // the tiles come out of one L2 instead of being fetched from HBM by up to eight
+    const unsigned nwg = gridDim.x * gridDim.y * gridDim.z;
+    const unsigned work = xcd_contiguous(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), nwg);
+    const int bx = (int)(work % gridDim.x), by = (int)((work / gridDim.x) % gridDim.y), b = (int)(work / (gridDim.x * gridDim.y));
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nq = nq_arr[b], nt = nt_arr[b];
-    const int q0 = (blockIdx.x * 2 + wave) * MF_QPW;               // first query column of this wavefront
-    if (blockIdx.x * 2 * MF_QPW >= nq) return;                       // workgroup-uniform
+    const int q0 = (bx * 2 + wave) * MF_QPW;                        // first query column of this wavefront
+    if (bx * 2 * MF_QPW >= nq) return;                                // workgroup-uniform
     __shared__ uint4 s_tile[2][8 * 64];                              // two train tiles of 8 KiB
     const int nTall = (nt + 31) >> 5, per = (nTall + nsplit - 1) / nsplit;
-    const int t_lo = min((int)blockIdx.y * per, nTall), nT = min(t_lo + per, nTall) - t_lo;   // tiles [t_lo, t_lo + nT)
+    const int t_lo = min(by * per, nTall), nT = min(t_lo + per, nTall) - t_lo;   // tiles [t_lo, t_lo + nT)
     const uint4* et = Et + ((size_t)b * tiles_cap + t_lo) * 512;
     // B operands: this wavefront's two query blocks, 8 k-steps each (columns past nq hold zero bytes or stale tiles; never written out)
     v4i bq[2][8];
@@ -219,7 +224,7 @@ void hamming_mfma_k(const uint4* __restrict__ Eq, const int32_t* __restrict__ nq
         // keys carry 2 * Hamming: back to (Hamming << 16 | row), the form knn2_finalize reads
         const uint32_t kb = best[blk] == KEY_NONE ? KEY_NONE : ((best[blk] >> 17) << 16) | (best[blk] & 0xFFFFu);
         const uint32_t ks = second[blk] == KEY_NONE ? KEY_NONE : ((second[blk] >> 17) << 16) | (second[blk] & 0xFFFFu);
-        if (lane < 32 && qi < nq) part[((size_t)b * nsplit + blockIdx.y) * cap + qi] = make_uint2(kb, ks);
+        if (lane < 32 && qi < nq) part[((size_t)b * nsplit + by) * cap + qi] = make_uint2(kb, ks);
     }
 }
 
