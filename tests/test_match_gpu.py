@@ -110,3 +110,23 @@ def test_batched_device_path_with_ratio(ctx, oracle):
         np.testing.assert_array_equal(hq[b, : mcount[b]], oq)
         np.testing.assert_array_equal(ht[b, : mcount[b]], ot)
         np.testing.assert_array_equal(hd[b, : mcount[b]], od)
+
+
+def test_valu_matcher_kept_for_comparison_still_matches_the_oracle():
+    """MSLAM_MATCH_MFMA=0 selects the xor/popcount kernel (the switch is read once per process, so this runs in a child)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import numpy as np\n"
+        "from monocular_slam_amd import api\n"
+        "from oracle import binding as ob\n"
+        "ctx = api.Context(0, 640, 480, 4096, 1)\n"
+        "rng = np.random.default_rng(3)\n"
+        "for nq, nt in ((2000, 2000), (257, 255), (33, 700), (1, 2)):\n"
+        "    q = rng.integers(0, 256, size=(nq, 32), dtype=np.uint8); t = rng.integers(0, 256, size=(nt, 32), dtype=np.uint8)\n"
+        "    t[:min(nq, nt) // 2] = q[:min(nq, nt) // 2]\n"
+        "    idx, dist = ctx.match_knn2(q, t); rc, oi, od = ob.match_knn2(q, t)\n"
+        "    assert rc == 0 and (idx == oi).all() and (dist == od).all(), (nq, nt)\n"
+        "ctx.close(); print('ok')\n")
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, MSLAM_MATCH_MFMA="0"), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-2000:]
