@@ -37,7 +37,7 @@ def test_ragged_sizes(ctx, oracle, nq, nt):
     _check(ctx, oracle, q, t)
 
 
-@pytest.mark.parametrize("nq,nt", [(31, 33), (32, 32), (33, 31), (127, 129), (128, 128), (129, 96), (2000, 95), (95, 2000), (1999, 2017), (65, 4095)])
+@pytest.mark.parametrize("nq,nt", [(31, 33), (32, 32), (33, 31), (127, 129), (128, 128), (129, 96), (2000, 95), (95, 2000), (1999, 2017), (65, 4095), (9000, 10000)])
 def test_sizes_around_the_mfma_tiles(ctx, oracle, nq, nt):
     """The matcher works on tiles of 32 train rows x 64 query columns per wavefront and cuts the train tiles into shares
     (hamming_mfma_k): sizes one off the tile, wavefront and workgroup boundaries, shares with no tile at all (nt = 95 with 4
