@@ -243,7 +243,22 @@ def main():
             out = [torch.empty(PNP_H, dtype=torch.int32) for _ in range(world)]
             dist.all_gather(out, torch.from_numpy(c.copy()))
 
-    ev_ctx = tbs[0].ctx
+    # step-time distribution: a timing stream of its own waits (on the device) for every stream that carries work of a step --
+    # both sub-batches' extract+match streams and their PnP streams -- and records one event per step; no host sync inside the
+    # loop and no dependency between the working streams
+    ev_ctx = api.Context(local_rank, W, H, 64, 1)
+    step_streams = []
+    for tb in tbs:
+        step_streams.append(tb.ctx)
+        if tb.pnp_ctx is not tb.ctx:
+            step_streams.append(tb.pnp_ctx)
+    fence_evs = [[c.event() for c in step_streams] for _ in range(2)]
+
+    def step_fence(k, ev):
+        for c, e in zip(step_streams, fence_evs[k & 1]):
+            c.record(e)
+            ev_ctx.wait_event(e)
+        ev_ctx.record(ev)
 
     def step():
         for _ in range(T):
@@ -262,12 +277,20 @@ def main():
     barrier()
     # per-step HIP events on the first sub-batch's stream (no host sync inside the loop): step-time distribution
     evs = [ev_ctx.event() for _ in range(args.steps + 1)]
-    ev_ctx.record(evs[0])
+    step_fence(0, evs[0])
     t0 = time.perf_counter()
+    # At most IN_FLIGHT steps are enqueued ahead of the device.  The four streams of a rank are independent (the PnP chain does
+    # not consume the match), so an unbounded host lets the PnP streams finish all K steps while the extract+match streams
+    # are at step K/2: the wall time is the same (measured: 26.0 ms per step for depths 1, 2, 4, 8 and unbounded), but the
+    # per-step times then say 30 ms for the first half and 22.6 ms for the second.  Bounded, every step is a whole step.
+    depth = max(1, int(os.environ.get("BENCH_IN_FLIGHT", "2")))
     for k in range(args.steps):
+        if k >= depth:
+            ev_ctx.elapsed_ms(evs[0], evs[k - depth + 1])   # host waits for the fence of step k - depth
         step()
-        ev_ctx.record(evs[k + 1])
+        step_fence(k + 1, evs[k + 1])
     barrier()
+    ev_ctx.sync()
     elapsed = time.perf_counter() - t0
     if dist is not None:
         import torch
@@ -275,6 +298,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     step_ms = [ev_ctx.elapsed_ms(evs[k], evs[k + 1]) for k in range(args.steps)]
+    if os.environ.get("BENCH_DUMP_STEPS") and rank == 0:
+        print("step_ms:", " ".join("%.2f" % v for v in step_ms), file=sys.stderr)
 
     # ---- outputs of the timed configuration: status / counts, then parity against the oracle (outside the timed region)
     ok = True
@@ -391,7 +416,7 @@ def main():
             "timed_seconds": elapsed,
             "step_ms": {"median": pct(step_ms, 50), "p10": pct(step_ms, 10), "p90": pct(step_ms, 90), "n": len(step_ms),
                         "frames_per_s_median": B * T / (pct(step_ms, 50) * 1e-3),
-                        "how": "HIP events on sub-batch 0's stream after every step, no host sync inside the loop"},
+                        "how": "one HIP event per step on a timing stream that waits on the device for all working streams of the step (extract+match and PnP of every sub-batch); the host stays at most 2 steps ahead (BENCH_IN_FLIGHT)"},
             "valid_outputs": ok,
             "runtime_libs": api.loaded_runtime_libs(),
         }
