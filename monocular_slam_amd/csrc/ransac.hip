@@ -25,7 +25,6 @@
 
 namespace {
 
-constexpr int HT = 16;             // hypotheses per scoring workgroup
 constexpr int SCORE_THREADS = 256;
 
 // ------------------------------------------------------------------ small linear algebra
@@ -1446,7 +1445,6 @@ int mslam_fmat_ransac8_batch_dev(mslam_ctx* ctx, const double* x1, const double*
     a.models_s = (double*)(base + o_mods);
     a.counts = inlier_counts ? inlier_counts : (int32_t*)(base + o_cnt);
     a.best = best_h; a.F = F; a.status = status; a.n_inliers = n_inliers;
-    hipStream_t st = ctx->stream;
     // With an adaptive bound (0 < confidence < 1, the reference's 0.85) only the hypotheses before the point where the
     // sequential RANSAC loop would stop can win, typically a few dozen of H.  Unless the caller asks for every count, the
     // hypotheses go out in growing ranges and each range's select pass carries {niters, best, maxgood} to the next: blocks
@@ -1531,7 +1529,6 @@ int mslam_pnp_ransac_batch_dev(mslam_ctx* ctx, const double* X, const double* x,
     a.counts = inlier_counts ? inlier_counts : (int32_t*)(base + o_cnt);
     a.best = best_h; a.best_cnt = (int32_t*)(base + o_bc);
     a.Rt = Rt; a.rvec = rvec; a.tvec = tvec; a.inliers = inliers; a.n_inliers = n_inliers; a.status = nullptr;
-    hipStream_t st = ctx->stream;
     LAUNCH(ctx, K_PNP_PREPARE, pnp_prepare_k, dim3((capP + 255) / 256, B), dim3(256), 0, a);
     LAUNCH(ctx, K_PNP_SOLVE, pnp_solve_k, dim3((H + 63) / 64, B), dim3(64), 0, a);
     LAUNCH(ctx, K_PNP_SCORE, pnp_score_k, dim3((H + PNP_HPB - 1) / PNP_HPB, B), dim3(SCORE_THREADS), 0, a);
