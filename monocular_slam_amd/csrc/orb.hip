@@ -121,14 +121,30 @@ void resize_k(const uint8_t* __restrict__ src, int spitch, long long sfstride,
     const int sx_lo = xtab[x0].x & 0xFFFF, sx_hi = (int)((unsigned)xtab[xl].x >> 16);
     const int sy_lo = ytab[y0].x, sy_hi = ytab[yl].y;
     const int sxa = sx_lo & ~3;
-    const int ndw = ((sx_hi - sxa) >> 2) + 1, nrows = sy_hi - sy_lo + 1;
+    const int nrows = sy_hi - sy_lo + 1;
+    // LDS-DMA staging (16-byte chunks, lane-linear in LDS = row-major with a pitch of cpr chunks) whenever the last chunk of a
+    // row stays inside the row's pitch; the tile column at the right border falls back to dword loads through VGPRs
+    const int cpr = ((sx_hi - sxa) >> 4) + 1;
+    const bool dma = sxa + cpr * 16 <= spitch;
+    const int ndw = dma ? cpr * 4 : ((sx_hi - sxa) >> 2) + 1;
     const bool use_lds = ndw * nrows < RS_LDS_DW && nrows <= RS_HROWS && ndw <= 128; // true for pyramid scales up to ~1.6
     const uint8_t* sb = src + b * sfstride;
     const int tx = tid & 63, ty = tid >> 6;
     const int x4 = x0 + tx * 4;
     uint8_t* db = dst + b * dfstride;
     if (use_lds) {
-        {   // stage the footprint: 128 lanes per source row, two rows per pass, RS_HROWS / 2 passes; all loads of a lane are
+        if (dma) {   // nrows * cpr chunks: one global_load_lds_dwordx4 moves 64 of them, no VGPR round trip
+            const int nch = nrows * cpr, inv = (65536 + cpr - 1) / cpr;   // c / cpr == (c * inv) >> 16 for c < 640, cpr < 40
+            const uint8_t* s0 = sb + (size_t)sy_lo * spitch + sxa;
+            for (int c0 = 0; c0 < nch; c0 += 256) {
+                const int cb = c0 + (tid & ~63);     // wave-uniform first chunk of this instruction
+                const int c = cb + (tid & 63);
+                if (c < nch) {
+                    const int r = (int)(__umul24((unsigned)c, (unsigned)inv) >> 16), k = c - __mul24(r, cpr);
+                    glds16(s0 + __umul24((unsigned)r, (unsigned)spitch) + 16 * k, reinterpret_cast<uint8_t*>(s_src) + cb * 16);
+                }
+            }
+        } else {   // stage the footprint: 128 lanes per source row, two rows per pass, RS_HROWS / 2 passes; all loads of a lane are
             // issued before its first LDS store (one memory latency per tile, not one per pass)
             const int max_dw = spitch / 4 - 1, spitch_dw = spitch / 4;
             const uint32_t* sb32 = reinterpret_cast<const uint32_t*>(sb);
@@ -252,7 +268,20 @@ void pyramid2_k(Pyr2Args a)
     const int sy_lo = a.ytA[oy0].x, sy_hi = a.ytA[cy1].y;
     const int sxa = sx_lo & ~3;
     const int ndw = ((sx_hi - sxa) >> 2) + 1, nrows = sy_hi - sy_lo + 1;   // <= P2_SDW, P2_SH
-    {
+    const int cprn = (ndw + 3) >> 2;                       // 16-byte chunks of a source row that hold needed columns
+    if (sxa + 16 * cprn <= a.spitch) {
+        // LDS-DMA: the LDS row pitch is P2_SDW dwords = 14 chunks, so chunk c of the lane-linear destination is (row c / 14,
+        // chunk c % 14); chunks past the needed columns are masked off.  No VGPR round trip, 2 instructions per wavefront.
+        static_assert(P2_SDW % 4 == 0, "whole 16-byte chunks per LDS row");
+        constexpr int CPR = P2_SDW / 4;
+        const uint8_t* s0 = a.S + b * a.sfstride + (size_t)sy_lo * a.spitch + sxa;
+        const int nch = nrows * CPR;
+        for (int c0 = 0; c0 < nch; c0 += 256) {
+            const int cb = c0 + (tid & ~63), c = cb + (tid & 63);
+            const int r = c / CPR, k = c - r * CPR;
+            if (c < nch && k < cprn) glds16(s0 + __umul24((unsigned)r, (unsigned)a.spitch) + 16 * k, reinterpret_cast<uint8_t*>(s_src) + cb * 16);
+        }
+    } else {   // the tile column at the right border: a chunk would cross the end of the row
         const uint32_t* sb32 = reinterpret_cast<const uint32_t*>(a.S + b * a.sfstride);
         const int max_dw = a.spitch / 4 - 1, spitch_dw = a.spitch / 4;
         for (int i = tid; i < nrows * P2_SDW; i += 256) {
