@@ -722,8 +722,7 @@ void select_k(OrbDev od)
 // ---------------------------------------------------------------- K4-K6: describe
 constexpr int DP_R = 21;               // raw patch radius: 18 (pattern reach) + 3 (blur)
 constexpr int DP_N = 2 * DP_R + 1;     // 43
-constexpr int DP_PITCH = 52;           // LDS bytes per raw row (13 dwords: odd, so a column of rows is bank-conflict free)
-constexpr int DP_ROW_DW = 12;          // dwords actually loaded per row (45 bytes + misalignment)
+constexpr int DP_PITCH = 48;           // LDS bytes per raw row: three 16-byte LDS-DMA chunks (45 bytes + misalignment)
 constexpr int DB_N = 37;               // blurred patch side (radius 18)
 constexpr int DH_RP = 22, DH_CG = 10;  // row pass: 22 row pairs x 10 groups of 4 columns (44 x 40 >= 43 x 37)
 constexpr int HT_DW = 23;              // dwords per column of the transposed row-pass result (46 u16 rows; odd)
@@ -760,7 +759,7 @@ struct DescArgs {
 __global__ __launch_bounds__(64 * DESC_WAVES)
 void describe_k(OrbDev od, DescArgs out)
 {
-    __shared__ uint32_t s_raw[DESC_WAVES][2 * DH_RP * DP_PITCH / 4];
+    __shared__ uint32_t s_raw[DESC_WAVES][2 * DH_RP * DP_PITCH / 4 + 4];   // (+4: the last row's column groups read a dword past it)
     __shared__ uint32_t s_h[DESC_WAVES][4 * DH_CG * HT_DW];
     __shared__ uint32_t s_blur[DESC_WAVES][DB_N * BT_DW];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -789,26 +788,19 @@ void describe_k(OrbDev od, DescArgs out)
     const uint2 sel = active ? od.sel[((size_t)b * od.L + l) * od.max_kpts + (g - off)] : make_uint2((DP_R << 12) | DP_R, 0);
     const int x = (int)(sel.x & 0xFFF), y = (int)(sel.x >> 12);
     const uint8_t* img = lv.img + b * lv.frame_stride;
-    // ---- raw 43x43 patch via aligned dword loads (always inside the image: edge >= 22)
+    // ---- raw 43x43 patch by LDS-DMA (always inside the image: edge >= 22): 43 rows x 3 chunks of 16 bytes from the dword-aligned
+    // column xa, lane-linear in LDS = row-major with a pitch of 48 bytes; 3 instructions per keypoint, no VGPR round trip.
+    // A chunk may run up to 4 bytes past the end of an image row into the next one (rows <= h - 2 here): columns nothing reads.
     const int px0 = x - DP_R, py0 = y - DP_R;
     const int xa = px0 & ~3, xo = px0 & 3;
-    const int max_dw = lv.pitch / 4 - 1;
     uint32_t* raw32 = s_raw[wave];
-    {   // 5 rows x 12 dwords per pass (60 of 64 lanes), 9 passes; loads first, then the LDS stores
-        const int r0 = lane / DP_ROW_DW, c = lane - r0 * DP_ROW_DW;
-        const uint32_t* img32 = reinterpret_cast<const uint32_t*>(img);
-        const int pitch_dw = lv.pitch / 4;
-        const unsigned col = (unsigned)min(xa / 4 + c, max_dw);
-        uint32_t v[9];
+    {
+        constexpr int NCH = DP_N * (DP_PITCH / 16);
+        const uint8_t* g0 = img + (size_t)py0 * lv.pitch + xa;
 #pragma unroll
-        for (int k = 0; k < 9; k++) {
-            const int r = r0 + 5 * k;
-            v[k] = (active && lane < 60 && r < DP_N) ? img32[__umul24((unsigned)(py0 + r), (unsigned)pitch_dw) + col] : 0u;
-        }
-#pragma unroll
-        for (int k = 0; k < 9; k++) {
-            const int r = r0 + 5 * k;
-            if (lane < 60 && r < DP_N) raw32[r * (DP_PITCH / 4) + c] = v[k];
+        for (int c0 = 0; c0 < NCH; c0 += 64) {
+            const int c = c0 + lane, r = c / (DP_PITCH / 16), k = c - r * (DP_PITCH / 16);
+            if (active && c < NCH) glds16(g0 + __umul24((unsigned)r, (unsigned)lv.pitch) + 16 * k, reinterpret_cast<uint8_t*>(raw32) + c0 * 16);
         }
     }
     __syncthreads();
