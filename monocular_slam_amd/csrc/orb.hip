@@ -43,7 +43,44 @@ __constant__ int8_t c_pattern[256 * 4] = {
 #include "orb_pattern_31.inc"
 };
 // u_max of IC_Angle for half patch 15 (OpenCV computeKeyPoints)
-__constant__ int c_umax[16] = { 15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3 };
+// half widths of the circular patch rows (ORB's umax for patch size 31): { 15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3 },
+// baked into the weight bytes below (tools/gen_pattern.py style: generated, not edited by hand)
+// IC_Angle weights per (|v|, half of the row): 4 dwords of (u + 15) bytes for the columns inside the circular patch (0 outside),
+// then 4 dwords of 0/1 bytes (inside / outside); half 0 = columns -15..0, half 1 = columns 1..16
+__constant__ uint32_t c_icw[32][8] = {
+    { 0x03020100u, 0x07060504u, 0x0b0a0908u, 0x0f0e0d0cu, 0x01010101u, 0x01010101u, 0x01010101u, 0x01010101u },
+    { 0x13121110u, 0x17161514u, 0x1b1a1918u, 0x001e1d1cu, 0x01010101u, 0x01010101u, 0x01010101u, 0x00010101u },
+    { 0x03020100u, 0x07060504u, 0x0b0a0908u, 0x0f0e0d0cu, 0x01010101u, 0x01010101u, 0x01010101u, 0x01010101u },
+    { 0x13121110u, 0x17161514u, 0x1b1a1918u, 0x001e1d1cu, 0x01010101u, 0x01010101u, 0x01010101u, 0x00010101u },
+    { 0x03020100u, 0x07060504u, 0x0b0a0908u, 0x0f0e0d0cu, 0x01010101u, 0x01010101u, 0x01010101u, 0x01010101u },
+    { 0x13121110u, 0x17161514u, 0x1b1a1918u, 0x001e1d1cu, 0x01010101u, 0x01010101u, 0x01010101u, 0x00010101u },
+    { 0x03020100u, 0x07060504u, 0x0b0a0908u, 0x0f0e0d0cu, 0x01010101u, 0x01010101u, 0x01010101u, 0x01010101u },
+    { 0x13121110u, 0x17161514u, 0x1b1a1918u, 0x001e1d1cu, 0x01010101u, 0x01010101u, 0x01010101u, 0x00010101u },
+    { 0x03020100u, 0x07060504u, 0x0b0a0908u, 0x0f0e0d0cu, 0x01010100u, 0x01010101u, 0x01010101u, 0x01010101u },
+    { 0x13121110u, 0x17161514u, 0x1b1a1918u, 0x00001d1cu, 0x01010101u, 0x01010101u, 0x01010101u, 0x00000101u },
+    { 0x03020100u, 0x07060504u, 0x0b0a0908u, 0x0f0e0d0cu, 0x01010100u, 0x01010101u, 0x01010101u, 0x01010101u },
+    { 0x13121110u, 0x17161514u, 0x1b1a1918u, 0x00001d1cu, 0x01010101u, 0x01010101u, 0x01010101u, 0x00000101u },
+    { 0x03020100u, 0x07060504u, 0x0b0a0908u, 0x0f0e0d0cu, 0x01010100u, 0x01010101u, 0x01010101u, 0x01010101u },
+    { 0x13121110u, 0x17161514u, 0x1b1a1918u, 0x00001d1cu, 0x01010101u, 0x01010101u, 0x01010101u, 0x00000101u },
+    { 0x03020000u, 0x07060504u, 0x0b0a0908u, 0x0f0e0d0cu, 0x01010000u, 0x01010101u, 0x01010101u, 0x01010101u },
+    { 0x13121110u, 0x17161514u, 0x1b1a1918u, 0x0000001cu, 0x01010101u, 0x01010101u, 0x01010101u, 0x00000001u },
+    { 0x03020000u, 0x07060504u, 0x0b0a0908u, 0x0f0e0d0cu, 0x01010000u, 0x01010101u, 0x01010101u, 0x01010101u },
+    { 0x13121110u, 0x17161514u, 0x1b1a1918u, 0x0000001cu, 0x01010101u, 0x01010101u, 0x01010101u, 0x00000001u },
+    { 0x03000000u, 0x07060504u, 0x0b0a0908u, 0x0f0e0d0cu, 0x01000000u, 0x01010101u, 0x01010101u, 0x01010101u },
+    { 0x13121110u, 0x17161514u, 0x1b1a1918u, 0x00000000u, 0x01010101u, 0x01010101u, 0x01010101u, 0x00000000u },
+    { 0x00000000u, 0x07060504u, 0x0b0a0908u, 0x0f0e0d0cu, 0x00000000u, 0x01010101u, 0x01010101u, 0x01010101u },
+    { 0x13121110u, 0x17161514u, 0x001a1918u, 0x00000000u, 0x01010101u, 0x01010101u, 0x00010101u, 0x00000000u },
+    { 0x00000000u, 0x07060500u, 0x0b0a0908u, 0x0f0e0d0cu, 0x00000000u, 0x01010100u, 0x01010101u, 0x01010101u },
+    { 0x13121110u, 0x17161514u, 0x00001918u, 0x00000000u, 0x01010101u, 0x01010101u, 0x00000101u, 0x00000000u },
+    { 0x00000000u, 0x07060000u, 0x0b0a0908u, 0x0f0e0d0cu, 0x00000000u, 0x01010000u, 0x01010101u, 0x01010101u },
+    { 0x13121110u, 0x17161514u, 0x00000018u, 0x00000000u, 0x01010101u, 0x01010101u, 0x00000001u, 0x00000000u },
+    { 0x00000000u, 0x07000000u, 0x0b0a0908u, 0x0f0e0d0cu, 0x00000000u, 0x01000000u, 0x01010101u, 0x01010101u },
+    { 0x13121110u, 0x17161514u, 0x00000000u, 0x00000000u, 0x01010101u, 0x01010101u, 0x00000000u, 0x00000000u },
+    { 0x00000000u, 0x00000000u, 0x0b0a0900u, 0x0f0e0d0cu, 0x00000000u, 0x00000000u, 0x01010100u, 0x01010101u },
+    { 0x13121110u, 0x00001514u, 0x00000000u, 0x00000000u, 0x01010101u, 0x00000101u, 0x00000000u, 0x00000000u },
+    { 0x00000000u, 0x00000000u, 0x00000000u, 0x0f0e0d0cu, 0x00000000u, 0x00000000u, 0x00000000u, 0x01010101u },
+    { 0x00121110u, 0x00000000u, 0x00000000u, 0x00000000u, 0x00010101u, 0x00000000u, 0x00000000u, 0x00000000u },
+};
 // 7x7 sigma=2 Gaussian, 8-bit fixed point (getGaussianKernel(7,2,CV_32F) * 256, cvRound)
 __constant__ int c_gk[7] = { 18, 34, 49, 55, 49, 34, 18 };
 
@@ -804,17 +841,24 @@ void describe_k(OrbDev od, DescArgs out)
         }
     }
     __syncthreads();
-    const uint8_t* raw = reinterpret_cast<const uint8_t*>(raw32) + xo; // raw[r*DP_PITCH + c], centre at (21,21)
-    // ---- IC_Angle: lane (v + 15) * 2 + half sums one half of row v of the circular patch (integer sums: any order)
+    // ---- IC_Angle: lane (v + 15) * 2 + half sums one half of row v of the circular patch (integer sums: any order) with packed
+    // dot products: sum (u + 15) I(u) and sum I(u) over the half row's 16 columns against the weight bytes of c_icw (zero
+    // outside the circle); m10 = the first minus 15 times the second
     int m10 = 0, m01 = 0;
     if (lane < 62) {
         const int v = (lane >> 1) - 15, half = lane & 1;
-        const int dmax = c_umax[abs(v)];
-        const uint8_t* row = raw + (DP_R + v) * DP_PITCH + DP_R;
-        int rs = 0;
-        const int u0 = half ? 1 : -dmax, u1 = half ? dmax : 0;
-        for (int u = u0; u <= u1; u++) { const int val = row[u]; m10 += __mul24(u, val); rs += val; }   // v_mad_i32_i24
-        m01 = __mul24(v, rs);
+        const int start = (DP_R + v) * DP_PITCH + DP_R + (half ? 1 : -15) + xo;   // LDS byte of the half row's first column
+        const uint32_t* q = raw32 + (start >> 2);
+        const int sh = start & 3;
+        const uint32_t d0 = q[0], d1 = q[1], d2 = q[2], d3 = q[3], d4 = q[4];
+        const uint32_t e0 = __builtin_amdgcn_alignbyte(d1, d0, sh), e1 = __builtin_amdgcn_alignbyte(d2, d1, sh),
+                       e2 = __builtin_amdgcn_alignbyte(d3, d2, sh), e3 = __builtin_amdgcn_alignbyte(d4, d3, sh);
+        const uint4* wt = reinterpret_cast<const uint4*>(c_icw[abs(v) * 2 + half]);
+        const uint4 wx = wt[0], wm = wt[1];
+        const uint32_t sx = __builtin_amdgcn_udot4(e3, wx.w, __builtin_amdgcn_udot4(e2, wx.z, __builtin_amdgcn_udot4(e1, wx.y, __builtin_amdgcn_udot4(e0, wx.x, 0u, false), false), false), false);
+        const uint32_t rs = __builtin_amdgcn_udot4(e3, wm.w, __builtin_amdgcn_udot4(e2, wm.z, __builtin_amdgcn_udot4(e1, wm.y, __builtin_amdgcn_udot4(e0, wm.x, 0u, false), false), false), false);
+        m10 = (int)sx - 15 * (int)rs;
+        m01 = __mul24(v, (int)rs);
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { m10 += __shfl_xor(m10, o); m01 += __shfl_xor(m01, o); }
