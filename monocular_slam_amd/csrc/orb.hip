@@ -527,6 +527,8 @@ void fast_nms_k(OrbDev od)
         unsigned long long colok[4]; // lanes whose pixel 4g + k lies inside the needed score columns
 #pragma unroll
         for (int k = 0; k < 4; k++) colok[k] = __builtin_amdgcn_ballot_w64(4 * g + k < lim_x);
+        unsigned long long bal[FS_H / (FAST_THREADS / 32)][4];
+        int tot = 0;
 #pragma unroll
         for (int m = 0; m < FS_H / (FAST_THREADS / 32); m++) {
             const int sy = ry + (FAST_THREADS / 32) * m;
@@ -536,8 +538,6 @@ void fast_nms_k(OrbDev od)
             const uint32_t Tw = rowp[1 - 3 * (FP_PITCH / 4)], Bw = rowp[1 + 3 * (FP_PITCH / 4)];
             const uint32_t P4 = __builtin_amdgcn_alignbyte(Rw, Cw, 3);   // pixels at x + 3
             const uint32_t P12 = __builtin_amdgcn_alignbyte(Cw, Lw, 1);  // pixels at x - 3
-            unsigned long long bal[4];
-            int tot = 0;
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 const uint32_t v = byte_of(Cw, k);
@@ -547,19 +547,24 @@ void fast_nms_k(OrbDev od)
                 // (p0 > hi | p8 > hi) & (p4 > hi | p12 > hi)  ==  min(max(p0, p8), max(p4, p12)) > hi, and mirrored
                 const unsigned long long brig = __builtin_amdgcn_ballot_w64(min(max(p0, p8), max(p4, p12)) > hi);
                 const unsigned long long dark = __builtin_amdgcn_ballot_w64(max(min((int)p0, (int)p8), min((int)p4, (int)p12)) < lo);
-                bal[k] = (brig | dark) & rowok & colok[k];
-                tot += __popcll(bal[k]);
+                bal[m][k] = (brig | dark) & rowok & colok[k];
+                tot += __popcll(bal[m][k]);
             }
-            if (tot) { // wave-uniform
-                int base = 0;
-                if (lane == 0) base = atomicAdd(&s_n1, tot);
-                base = __shfl(base, 0);
+        }
+        // one reservation in the survivor list per wavefront (the 32 lane masks stay in SGPRs), then the entries by rank
+        if (tot) { // wave-uniform
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&s_n1, tot);
+            base = __shfl(base, 0);
+#pragma unroll
+            for (int m = 0; m < FS_H / (FAST_THREADS / 32); m++) {
+                const int sy = ry + (FAST_THREADS / 32) * m;
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     // rank of this lane among the survivors of slot k: v_mbcnt_lo/hi take the lane mask straight from SGPRs
-                    const int rank_k = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal[k] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal[k], 0u));
-                    if (__builtin_amdgcn_inverse_ballot_w64(bal[k])) s_list[base + rank_k] = (uint16_t)(sy * FS_W + 4 * g + k);
-                    base += __popcll(bal[k]);
+                    const int rank_k = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal[m][k] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal[m][k], 0u));
+                    if (__builtin_amdgcn_inverse_ballot_w64(bal[m][k])) s_list[base + rank_k] = (uint16_t)(sy * FS_W + 4 * g + k);
+                    base += __popcll(bal[m][k]);
                 }
             }
         }
