@@ -765,11 +765,8 @@ void select_k(OrbDev od)
 constexpr int DP_R = 21;               // raw patch radius: 18 (pattern reach) + 3 (blur)
 constexpr int DP_N = 2 * DP_R + 1;     // 43
 constexpr int DP_PITCH = 48;           // LDS bytes per raw row: three 16-byte LDS-DMA chunks (45 bytes + misalignment)
-constexpr int DB_N = 37;               // blurred patch side (radius 18)
 constexpr int DH_RP = 22, DH_CG = 10;  // row pass: 22 row pairs x 10 groups of 4 columns (44 x 40 >= 43 x 37)
 constexpr int HT_DW = 23;              // dwords per column of the transposed row-pass result (46 u16 rows; odd)
-constexpr int DV_RG = 10;              // column pass: 10 groups of 4 rows per column
-constexpr int BT_DW = 11;              // dwords per column of the transposed blurred patch (44 u8 rows; odd)
 constexpr int DESC_WAVES = 4;
 
 __device__ __forceinline__ float fast_atan2_deg(float y, float x)
@@ -803,7 +800,6 @@ void describe_k(OrbDev od, DescArgs out)
 {
     __shared__ uint32_t s_raw[DESC_WAVES][2 * DH_RP * DP_PITCH / 4 + 4];   // (+4: the last row's column groups read a dword past it)
     __shared__ uint32_t s_h[DESC_WAVES][4 * DH_CG * HT_DW];
-    __shared__ uint32_t s_blur[DESC_WAVES][DB_N * BT_DW];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const unsigned wg = xcd_contiguous(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y);
     const int b = (int)(wg / gridDim.x), bx = (int)(wg % gridDim.x);
@@ -898,29 +894,6 @@ void describe_k(OrbDev od, DescArgs out)
         }
     }
     __syncthreads();
-    uint32_t* blurT = s_blur[wave];
-    {
-        typedef unsigned short us2 __attribute__((ext_vector_type(2)));
-        const us2 G01 = {18, 34}, G23 = {49, 55}, G45 = {49, 34}, G6l = {18, 0}, G6h = {0, 18};
-#define DOT2(P, G, C) __builtin_amdgcn_udot2(__builtin_bit_cast(us2, (P)), (G), (C), false)
-        static_assert(DH_CG == 10 && DB_N == 37, "item steps below assume these sizes");
-        int rg = lane / DB_N, c = lane - rg * DB_N; // item = rg * DB_N + c advances by 64 = DB_N + 27
-        for (int i = lane; i < DB_N * DV_RG; i += 64, rg += 1, c += 27) {
-            if (c >= DB_N) { c -= DB_N; rg++; }
-            const uint32_t* q = hT + c * HT_DW + 2 * rg;
-            const uint32_t p0 = q[0], p1 = q[1], p2 = q[2], p3 = q[3], p4 = q[4];
-            const uint32_t q0 = __builtin_amdgcn_alignbyte(p1, p0, 2), q1 = __builtin_amdgcn_alignbyte(p2, p1, 2),
-                           q2 = __builtin_amdgcn_alignbyte(p3, p2, 2), q3 = __builtin_amdgcn_alignbyte(p4, p3, 2);
-            uint32_t o0 = DOT2(p3, G6l, DOT2(p2, G45, DOT2(p1, G23, DOT2(p0, G01, 1u << 15))));
-            uint32_t o1 = DOT2(q3, G6l, DOT2(q2, G45, DOT2(q1, G23, DOT2(q0, G01, 1u << 15))));
-            uint32_t o2 = DOT2(p4, G6l, DOT2(p3, G45, DOT2(p2, G23, DOT2(p1, G01, 1u << 15))));
-            uint32_t o3 = DOT2(p4, G6h, DOT2(q3, G45, DOT2(q2, G23, DOT2(q1, G01, 1u << 15))));
-            o0 = min(o0 >> 16, 255u); o1 = min(o1 >> 16, 255u); o2 = min(o2 >> 16, 255u); o3 = min(o3 >> 16, 255u);
-            blurT[c * BT_DW + rg] = o0 | (o1 << 8) | (o2 << 16) | (o3 << 24);
-        }
-#undef DOT2
-    }
-    __syncthreads();
     // ---- 256 rotated binary tests; test t = j*64 + lane, ballot j = descriptor bytes 8j..8j+7
     float ang = angle;
     ang *= (float)(3.1415926535897932384626433832795 / 180.f);
@@ -929,15 +902,32 @@ void describe_k(OrbDev od, DescArgs out)
     double sd, cd;
     mslam_sincos_2pi((double)ang, &sd, &cd);
     const float ca = (float)cd, sb = (float)sd;
-    const uint8_t* centre = reinterpret_cast<const uint8_t*>(blurT) + 18 * (BT_DW * 4) + 18; // [x][y]
+    // The column pass of the blur is evaluated only where the tests look: the blurred pixel (c, r) (column / row offsets
+    // 0..36 from the patch corner) is min((sum_k g[k] hT[c][r + k] + 2^15) >> 16, 255), seven vertical neighbours that sit in
+    // four consecutive dwords of the transposed row-pass result; an odd r starts in the high half of the first dword, which the
+    // weight pairs absorb ({0,18},{34,49},{55,49},{34,18} instead of {18,34},{49,55},{49,34},{18,0}).  512 samples per
+    // keypoint instead of the 37 x 37 blurred patch (1369 pixels): the same integers, fewer of them.
+    typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+    auto blurred = [&](int cx, int ry) -> int {   // cx, ry in [-18, 18] (pattern reach), relative to the keypoint
+        const int c = cx + 18, r = ry + 18;
+        const uint32_t* q = hT + __mul24(c, HT_DW) + (r >> 1);
+        const bool odd = r & 1;
+        const uint32_t w0 = odd ? (18u << 16) : (18u | (34u << 16)), w1 = odd ? (34u | (49u << 16)) : (49u | (55u << 16)),
+                       w2 = odd ? (55u | (49u << 16)) : (49u | (34u << 16)), w3 = odd ? (34u | (18u << 16)) : 18u;
+        uint32_t o = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, q[0]), __builtin_bit_cast(us2, w0), 1u << 15, false);
+        o = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, q[1]), __builtin_bit_cast(us2, w1), o, false);
+        o = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, q[2]), __builtin_bit_cast(us2, w2), o, false);
+        o = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, q[3]), __builtin_bit_cast(us2, w3), o, false);
+        return (int)min(o >> 16, 255u);
+    };
     unsigned long long bits[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         const int8_t* pt = c_pattern + (j * 64 + lane) * 4;
         float x0 = pt[0] * ca - pt[1] * sb, y0 = pt[0] * sb + pt[1] * ca;
         float x1 = pt[2] * ca - pt[3] * sb, y1 = pt[2] * sb + pt[3] * ca;
-        int t0 = centre[__mul24(__float2int_rn(x0), BT_DW * 4) + __float2int_rn(y0)];
-        int t1 = centre[__mul24(__float2int_rn(x1), BT_DW * 4) + __float2int_rn(y1)];
+        const int t0 = blurred(__float2int_rn(x0), __float2int_rn(y0));
+        const int t1 = blurred(__float2int_rn(x1), __float2int_rn(y1));
         bits[j] = __ballot(t0 < t1);
     }
     if (!active) return;
