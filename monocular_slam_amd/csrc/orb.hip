@@ -601,11 +601,14 @@ void fast_nms_k(OrbDev od)
         const int i = s_list[j];
         const int sy = i / FS_W, sx = i % FS_W;
         const int sc = s_score[i];
-        if (sc == 0 || sx < out_x0 || sy < 1 || sx > out_w || sy > out_h) continue;
-        const uint8_t* c = s_score + i;
-        const bool mx = sc > c[-1] && sc > c[1] && sc > c[-FS_W - 1] && sc > c[-FS_W] && sc > c[-FS_W + 1] &&
-                        sc > c[FS_W - 1] && sc > c[FS_W] && sc > c[FS_W + 1];
-        if (mx) {
+        // branch-free: eight neighbour bytes, their maximum by v_max3, one compare (a chain of && here compiles to a chain of
+        // exec-mask branches that every wavefront walks to the end); positions that are no candidates read a safe interior cell
+        const bool cand = (sc != 0) & (sx >= out_x0) & (sy >= 1) & (sx <= out_w) & (sy <= out_h);
+        const uint8_t* c = s_score + (cand ? i : FS_W + 1);
+        const uint32_t m0 = max(max((uint32_t)c[-FS_W - 1], (uint32_t)c[-FS_W]), (uint32_t)c[-FS_W + 1]);
+        const uint32_t m1 = max(max((uint32_t)c[-1], (uint32_t)c[1]), (uint32_t)c[FS_W - 1]);
+        const uint32_t m2 = max(max((uint32_t)c[FS_W], (uint32_t)c[FS_W + 1]), m0);
+        if (cand & ((uint32_t)sc > max(m1, m2))) {
             const int e = atomicAdd(&s_ne, 1);
             const int gx = ox - 1 + sx, gy = oy - 1 + sy;
             s_emit[e] = ((uint32_t)sc << 24) | ((uint32_t)gy << 12) | (uint32_t)gx;
