@@ -202,11 +202,15 @@ void resize_k(const uint8_t* __restrict__ src, int spitch, long long sfstride,
         }
         __syncthreads();
         int o0[4], a0[4], a1[4];
+        {   // the table is padded with copies of its last column: one group of 4 = two 16-byte loads, no clamps
+            const int4* t4 = reinterpret_cast<const int4*>(xtab + min(x4, (dw + 3) & ~3));
+            const int4 ta = t4[0], tb = t4[1];
+            const int tx_[4] = { ta.x, ta.z, tb.x, tb.z }, ty_[4] = { ta.y, ta.w, tb.y, tb.w };
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int2 t = xtab[min(x4 + i, dw - 1)];
-            // sx1 == sx0 + 1 except at the clamped right border, where a1 == 0 (fx = 0): reading sx0 + 1 is then harmless
-            o0[i] = (t.x & 0xFFFF) - sxa; a0[i] = t.y & 0xFFFF; a1[i] = (int)((unsigned)t.y >> 16);
+            for (int i = 0; i < 4; i++) {
+                // sx1 == sx0 + 1 except at the clamped right border, where a1 == 0 (fx = 0): reading sx0 + 1 is then harmless
+                o0[i] = (tx_[i] & 0xFFFF) - sxa; a0[i] = ty_[i] & 0xFFFF; a1[i] = (int)((unsigned)ty_[i] >> 16);
+            }
         }
         const uint8_t* lds = reinterpret_cast<const uint8_t*>(s_src);
         const int lpitch = ndw * 4;
@@ -332,10 +336,12 @@ void pyramid2_k(Pyr2Args a)
         const int g = tid % 44, rl = tid / 44;
         if (rl < 5 && 4 * g < caw) {
             int o0[4], a0[4], a1[4];
+            {
+                const int4* t4 = reinterpret_cast<const int4*>(a.xtA + ox0 + 4 * g);   // padded table: no clamps
+                const int4 ta = t4[0], tb = t4[1];
+                const int tx_[4] = { ta.x, ta.z, tb.x, tb.z }, ty_[4] = { ta.y, ta.w, tb.y, tb.w };
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const int2 t = a.xtA[min(ox0 + 4 * g + i, a.wA - 1)];
-                o0[i] = (t.x & 0xFFFF) - sxa; a0[i] = t.y & 0xFFFF; a1[i] = (int)((unsigned)t.y >> 16);
+                for (int i = 0; i < 4; i++) { o0[i] = (tx_[i] & 0xFFFF) - sxa; a0[i] = ty_[i] & 0xFFFF; a1[i] = (int)((unsigned)ty_[i] >> 16); }
             }
             const uint8_t* lds = reinterpret_cast<const uint8_t*>(s_src);
             for (int r = rl; r < nrows; r += 5) {
@@ -379,10 +385,12 @@ void pyramid2_k(Pyr2Args a)
         const int g = tid & 31, rl = tid >> 5;
         if (xB0 + 4 * g <= xB1) {
             int o0[4], a0[4], a1[4];
+            {
+                const int4* t4 = reinterpret_cast<const int4*>(a.xtB + xB0 + 4 * g);   // padded table: no clamps
+                const int4 ta = t4[0], tb = t4[1];
+                const int tx_[4] = { ta.x, ta.z, tb.x, tb.z }, ty_[4] = { ta.y, ta.w, tb.y, tb.w };
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const int2 t = a.xtB[min(xB0 + 4 * g + i, a.wB - 1)];
-                o0[i] = (t.x & 0xFFFF) - ox0; a0[i] = t.y & 0xFFFF; a1[i] = (int)((unsigned)t.y >> 16);
+                for (int i = 0; i < 4; i++) { o0[i] = (tx_[i] & 0xFFFF) - ox0; a0[i] = ty_[i] & 0xFFFF; a1[i] = (int)((unsigned)ty_[i] >> 16); }
             }
             const uint8_t* lds = reinterpret_cast<const uint8_t*>(s_A);
             for (int r = rl; r < cah; r += 8) {
@@ -1075,7 +1083,7 @@ static int orb_plan_get(mslam_ctx* ctx, int w, int h, int B, int channels, const
         off_cand[l] = reserve(sizeof(uint32_t) * (size_t)lv.cand_cap * B);
         off_candA[l] = reserve(sizeof(uint32_t) * (size_t)lv.cand_cap * B);
         off_resp[l] = reserve(sizeof(float) * (size_t)lv.cand_cap * B);
-        off_xt[l] = reserve(sizeof(int2) * (size_t)lv.w);
+        off_xt[l] = reserve(sizeof(int2) * (align_up((size_t)lv.w, 4) + 4));   // padded: column groups of 4 load two int4 without clamps
         off_yt[l] = reserve(sizeof(int4) * (size_t)lv.h);
     }
     od.tiles_per_frame = tile_base;
@@ -1119,8 +1127,9 @@ static int orb_plan_get(mslam_ctx* ctx, int w, int h, int B, int channels, const
             const int a0 = sat_short_host(cv_round_host((1.f - fx) * 2048)), a1 = sat_short_host(cv_round_host(fx * 2048));
             xt[(size_t)dx] = make_int2(sx | (sx1 << 16), (a0 & 0xFFFF) | (a1 << 16)); // 0 <= a0, a1 <= 2048
         }
-        HIP_TRY(ctx, hipMemcpy(lv.xtab, xt.data(), sizeof(int2) * (size_t)dw, hipMemcpyHostToDevice));
         h_xt[(size_t)l] = xt;
+        xt.resize(align_up((size_t)dw, 4) + 4, xt.back());   // the device copy repeats the last column: groups of 4 need no clamp
+        HIP_TRY(ctx, hipMemcpy(lv.xtab, xt.data(), sizeof(int2) * xt.size(), hipMemcpyHostToDevice));
         tab.assign((size_t)dh, make_int4(0, 0, 0, 0));
         for (int dy = 0; dy < dh; dy++) {
             float fy = (float)((dy + 0.5) * scale_y - 0.5);
