@@ -104,6 +104,7 @@ struct LevelDesc {
     int cand_cap; uint32_t* cand; uint32_t* candA; float* respA;
     int nfeat; float sf, inv_sf;
     int2* xtab; int4* ytab;            // resize tables for producing THIS level from l-1
+    int4* p2col; int4* p2row;          // pyramid2_k with THIS level as B: two int4 per tile column / tile row (regions and footprints)
     int fused_with_next;               // 1: this level and the next one are produced together from level l-1 (pyramid2_k)
 };
 
@@ -284,6 +285,7 @@ struct Pyr2Args {
     const uint8_t* S; int spitch; long long sfstride;
     uint8_t* A; int wA, hA, apitch; long long afstride; const int2* xtA; const int4* ytA;
     uint8_t* Bm; int wB, hB, bpitch; long long bfstride; const int2* xtB; const int4* ytB;
+    const int4* colD; const int4* rowD;   // per tile column / row: {ox0, ox1, cx1, sx_lo}{sx_hi} / {oy0, oy1, cy1, sy_lo}{sy_hi}
 };
 __global__ __launch_bounds__(256)
 void pyramid2_k(Pyr2Args a)
@@ -295,18 +297,13 @@ void pyramid2_k(Pyr2Args a)
     const int tid = threadIdx.x, b = blockIdx.z;
     const int xB0 = blockIdx.x * P2_BW, yB0 = blockIdx.y * P2_BH;
     const int xB1 = min(xB0 + P2_BW, a.wB) - 1, yB1 = min(yB0 + P2_BH, a.hB) - 1;
-    const bool lastx = xB0 + P2_BW >= a.wB, lasty = yB0 + P2_BH >= a.hB;
-    // A region: owned = [ox0, ox1) x [oy0, oy1), computed = [ox0, cx1] x [oy0, cy1]
-    const int ox0 = blockIdx.x == 0 ? 0 : ((a.xtB[xB0].x & 0xFFFF) & ~3);
-    const int ox1 = lastx ? ((a.wA + 3) & ~3) : ((a.xtB[xB0 + P2_BW].x & 0xFFFF) & ~3);
-    const int cx1 = lastx ? a.wA - 1 : (int)((unsigned)a.xtB[xB1].x >> 16);
-    const int oy0 = blockIdx.y == 0 ? 0 : a.ytB[yB0].x;
-    const int oy1 = lasty ? a.hA : a.ytB[yB0 + P2_BH].x;
-    const int cy1 = lasty ? a.hA - 1 : a.ytB[yB1].y;
+    // A region: owned = [ox0, ox1) x [oy0, oy1), computed = [ox0, cx1] x [oy0, cy1], and its source footprint: from the
+    // per-tile descriptors the host derived from the tables (two independent 32-byte scalar loads)
+    const int4 c0 = a.colD[2 * blockIdx.x], c1 = a.colD[2 * blockIdx.x + 1];
+    const int4 r0 = a.rowD[2 * blockIdx.y], r1 = a.rowD[2 * blockIdx.y + 1];
+    const int ox0 = c0.x, ox1 = c0.y, cx1 = c0.z, sx_lo = c0.w, sx_hi = c1.x;
+    const int oy0 = r0.x, oy1 = r0.y, cy1 = r0.z, sy_lo = r0.w, sy_hi = r1.x;
     const int caw = cx1 - ox0 + 1, cah = cy1 - oy0 + 1;   // <= P2_AW, P2_AH (checked on the host against the tables)
-    // source footprint of the A region
-    const int sx_lo = a.xtA[ox0].x & 0xFFFF, sx_hi = (int)((unsigned)a.xtA[cx1].x >> 16);
-    const int sy_lo = a.ytA[oy0].x, sy_hi = a.ytA[cy1].y;
     const int sxa = sx_lo & ~3;
     const int ndw = ((sx_hi - sxa) >> 2) + 1, nrows = sy_hi - sy_lo + 1;   // <= P2_SDW, P2_SH
     const int cprn = (ndw + 3) >> 2;                       // 16-byte chunks of a source row that hold needed columns
@@ -1060,7 +1057,7 @@ static int orb_plan_get(mslam_ctx* ctx, int w, int h, int B, int channels, const
     size_t bytes = 0;
     auto reserve = [&](size_t n) { bytes = align_up(bytes, 256); size_t o = bytes; bytes += n; return o; };
     size_t off_img[MSLAM_MAX_LEVELS], off_cand[MSLAM_MAX_LEVELS], off_candA[MSLAM_MAX_LEVELS], off_resp[MSLAM_MAX_LEVELS],
-        off_xt[MSLAM_MAX_LEVELS], off_yt[MSLAM_MAX_LEVELS];
+        off_xt[MSLAM_MAX_LEVELS], off_yt[MSLAM_MAX_LEVELS], off_p2c[MSLAM_MAX_LEVELS], off_p2r[MSLAM_MAX_LEVELS];
     int tile_base = 0;
     for (int l = 0; l < L; l++) {
         LevelDesc& lv = od.lv[l];
@@ -1085,6 +1082,8 @@ static int orb_plan_get(mslam_ctx* ctx, int w, int h, int B, int channels, const
         off_resp[l] = reserve(sizeof(float) * (size_t)lv.cand_cap * B);
         off_xt[l] = reserve(sizeof(int2) * (align_up((size_t)lv.w, 4) + 4));   // padded: column groups of 4 load two int4 without clamps
         off_yt[l] = reserve(sizeof(int4) * (size_t)lv.h);
+        off_p2c[l] = reserve(sizeof(int4) * 2 * (size_t)((lv.w + 127) / 128));
+        off_p2r[l] = reserve(sizeof(int4) * 2 * (size_t)((lv.h + 15) / 16));
     }
     od.tiles_per_frame = tile_base;
     const size_t off_sel = reserve(sizeof(uint2) * (size_t)B * L * od.max_kpts);
@@ -1111,6 +1110,8 @@ static int orb_plan_get(mslam_ctx* ctx, int w, int h, int B, int channels, const
         lv.respA = (float*)(base + off_resp[l]);
         lv.xtab = (int2*)(base + off_xt[l]);
         lv.ytab = (int4*)(base + off_yt[l]);
+        lv.p2col = (int4*)(base + off_p2c[l]);
+        lv.p2row = (int4*)(base + off_p2r[l]);
         if (l == 0) continue;
         // resize(INTER_LINEAR) coefficient tables for level l-1 -> l (OpenCV 2.4.13 imgwarp.cpp)
         const int sw = od.lv[l - 1].w, sh = od.lv[l - 1].h, dw = lv.w, dh = lv.h;
@@ -1156,23 +1157,34 @@ static int orb_plan_get(mslam_ctx* ctx, int w, int h, int B, int channels, const
         const std::vector<int2>& xtA = h_xt[(size_t)l]; const std::vector<int4>& ytA = h_yt[(size_t)l];
         const std::vector<int2>& xtB = h_xt[(size_t)l + 1]; const std::vector<int4>& ytB = h_yt[(size_t)l + 1];
         bool ok = true;
+        // per tile column / row of B: the A region it owns and computes and that region's source footprint, so that a
+        // workgroup reads two descriptors instead of walking four tables with dependent loads
+        std::vector<int4> colD, rowD;
         for (int xB0 = 0; xB0 < Bv.w && ok; xB0 += P2_BW) {
             const int xB1 = std::min(xB0 + P2_BW, Bv.w) - 1;
             const bool lastx = xB0 + P2_BW >= Bv.w;
             const int ox0 = xB0 == 0 ? 0 : ((xtB[(size_t)xB0].x & 0xFFFF) & ~3);
+            const int ox1 = lastx ? ((A.w + 3) & ~3) : ((xtB[(size_t)xB0 + P2_BW].x & 0xFFFF) & ~3);
             const int cx1 = lastx ? A.w - 1 : (int)((unsigned)xtB[(size_t)xB1].x >> 16);
             const int needed_lo = xtB[(size_t)xB0].x & 0xFFFF;
             if (cx1 - ox0 + 1 > P2_AW || cx1 < ox0 || ox0 > needed_lo) { ok = false; break; }
             const int sx_lo = xtA[(size_t)ox0].x & 0xFFFF, sx_hi = (int)((unsigned)xtA[(size_t)cx1].x >> 16);
             if (((sx_hi - (sx_lo & ~3)) >> 2) + 1 > P2_SDW) ok = false;
+            colD.push_back(make_int4(ox0, ox1, cx1, sx_lo)); colD.push_back(make_int4(sx_hi, 0, 0, 0));
         }
         for (int yB0 = 0; yB0 < Bv.h && ok; yB0 += P2_BH) {
             const int yB1 = std::min(yB0 + P2_BH, Bv.h) - 1;
             const bool lasty = yB0 + P2_BH >= Bv.h;
             const int oy0 = yB0 == 0 ? 0 : ytB[(size_t)yB0].x;
+            const int oy1 = lasty ? A.h : ytB[(size_t)yB0 + P2_BH].x;
             const int cy1 = lasty ? A.h - 1 : ytB[(size_t)yB1].y;
             if (cy1 - oy0 + 1 > P2_AH || cy1 < oy0 || oy0 > ytB[(size_t)yB0].x) { ok = false; break; }
             if (ytA[(size_t)cy1].y - ytA[(size_t)oy0].x + 1 > P2_SH) ok = false;
+            rowD.push_back(make_int4(oy0, oy1, cy1, ytA[(size_t)oy0].x)); rowD.push_back(make_int4(ytA[(size_t)cy1].y, 0, 0, 0));
+        }
+        if (ok) {
+            HIP_TRY(ctx, hipMemcpy(od.lv[l + 1].p2col, colD.data(), sizeof(int4) * colD.size(), hipMemcpyHostToDevice));
+            HIP_TRY(ctx, hipMemcpy(od.lv[l + 1].p2row, rowD.data(), sizeof(int4) * rowD.size(), hipMemcpyHostToDevice));
         }
         od.lv[l].fused_with_next = ok ? 1 : 0;
     }
@@ -1232,7 +1244,7 @@ int mslam_orb_extract_batch_dev(mslam_ctx* ctx, const uint8_t* imgs, int B, int 
         if (d.fused_with_next) {   // levels l and l + 1 from level l - 1 in one launch
             const LevelDesc& e = od.lv[l + 1];
             Pyr2Args pa{ s.img, s.pitch, s.frame_stride, d.img, d.w, d.h, d.pitch, d.frame_stride, d.xtab, d.ytab,
-                         e.img, e.w, e.h, e.pitch, e.frame_stride, e.xtab, e.ytab };
+                         e.img, e.w, e.h, e.pitch, e.frame_stride, e.xtab, e.ytab, e.p2col, e.p2row };
             LAUNCH(ctx, K_PYRAMID2, pyramid2_k, dim3((e.w + P2_BW - 1) / P2_BW, (e.h + P2_BH - 1) / P2_BH, B), dim3(256), 0, pa);
             l++;
             continue;
