@@ -115,6 +115,8 @@ struct OrbDev {
     uint2* sel;       // [B][L][max_kpts]
     int32_t* sel_cnt; // [B][L]
     int32_t* frame_status; // [B]
+    const int4* fast_tiles; // [tiles_per_frame] {level, tile x, tile y, 0}: fast_nms_k's tile -> level map, built on the host
+    uint32_t tpf_magic;     // floor(2^32 / tiles_per_frame) + 1 (tiles_per_frame >= 2): workgroup / tiles_per_frame == __umulhi(workgroup, tpf_magic)
 };
 
 // LDS-DMA: 16 bytes per lane from a per-lane global address straight into LDS at (wave-uniform) lds_wave_base + lane * 16.
@@ -481,15 +483,14 @@ void fast_nms_k(OrbDev od)
     uint32_t* s_emit = s_pix;
     static_assert(((FT_W + 1) / 2) * ((FT_H + 1) / 2) * 4 <= FP_H * FP_PITCH, "emit buffer must fit in the pixel tile");
 
-    // tile -> (frame, level, tx, ty): blocks of one frame are consecutive
+    // tile -> (frame, level, tx, ty): blocks of one frame are consecutive, so an XCD works through whole frames (a 2-D grid
+    // with the frame in y, each frame's tiles dealt over the XCDs, measured 40 % slower).  One multiply-high instead of the
+    // division by tiles_per_frame, one descriptor load instead of a search over the levels and a division by tiles_x.
     const unsigned wg = xcd_contiguous(blockIdx.x, gridDim.x);
-    const int b = (int)(wg / (unsigned)od.tiles_per_frame);
-    int t = (int)(wg % (unsigned)od.tiles_per_frame);
-    int l = 0;
-    while (l + 1 < od.L && t >= od.lv[l + 1].tile_base) l++;
+    const int b = od.tiles_per_frame > 1 ? (int)__umulhi(wg, od.tpf_magic) : (int)wg;
+    const int4 td = od.fast_tiles[wg - (unsigned)b * (unsigned)od.tiles_per_frame];
+    const int l = td.x, tx = td.y, ty = td.z;
     const LevelDesc& lv = od.lv[l];
-    t -= lv.tile_base;
-    const int tx = t % lv.tiles_x, ty = t / lv.tiles_x;
     const int ox = lv.tile_x0 + tx * FT_W, oy = lv.roi_y0 + ty * FT_H; // first output pixel (ox % 4 == 1; ox <= roi_x0 for tx == 0)
     const uint8_t* img = lv.img + b * lv.frame_stride;
     const int tid = threadIdx.x;
@@ -1065,7 +1066,7 @@ static int orb_plan_get(mslam_ctx* ctx, int w, int h, int B, int channels, const
         float inv = 1 / s;
         lv.sf = s; lv.inv_sf = inv;
         lv.w = cv_round_host(w * inv); lv.h = cv_round_host(h * inv);
-        if (lv.w < 1 || lv.h < 1) return MSLAM_ERR_INVALID;
+        if (lv.w < 1 || lv.h < 1) { orb_plan_destroy(ctx); return MSLAM_ERR_INVALID; }   // (no half-built plan left for the cache check above)
         lv.pitch = (int)align_up((size_t)lv.w, 64);
         lv.frame_stride = (long long)lv.pitch * lv.h;
         off_img[l] = reserve((size_t)lv.frame_stride * B);
@@ -1086,6 +1087,12 @@ static int orb_plan_get(mslam_ctx* ctx, int w, int h, int B, int channels, const
         off_p2r[l] = reserve(sizeof(int4) * 2 * (size_t)((lv.h + 15) / 16));
     }
     od.tiles_per_frame = tile_base;
+    if (tile_base > 1) {   // fast_nms_k divides its workgroup index by tiles_per_frame with one multiply: (n * magic) >> 32 == n / tpf
+        // for every n of a launch while n * (magic * tpf - 2^32) < 2^32 (fails only beyond ~10^4 tiles x 64 frames: refused)
+        const uint64_t tpf = (uint64_t)tile_base, magic = (1ull << 32) / tpf + 1;
+        if (tpf * (uint64_t)B * (magic * tpf - (1ull << 32)) >= (1ull << 32)) { orb_plan_destroy(ctx); return MSLAM_ERR_INVALID; }
+    }
+    const size_t off_ft = reserve(sizeof(int4) * (size_t)std::max(tile_base, 1));
     const size_t off_sel = reserve(sizeof(uint2) * (size_t)B * L * od.max_kpts);
     const size_t n_cnt = (size_t)B * L;
     pl->counters_bytes = sizeof(uint32_t) * ((CNT_STRIDE + 1) * n_cnt + B);
@@ -1098,6 +1105,15 @@ static int orb_plan_get(mslam_ctx* ctx, int w, int h, int B, int channels, const
     od.sel_cnt = (int32_t*)(od.cnt + CNT_STRIDE * n_cnt);
     od.frame_status = od.sel_cnt + n_cnt;
     od.sel = (uint2*)(base + off_sel);
+    {   // fast_nms_k's tile map
+        std::vector<int4> ft;
+        for (int l = 0; l < L; l++)
+            for (int ty = 0; ty < od.lv[l].tiles_y; ty++)
+                for (int tx = 0; tx < od.lv[l].tiles_x; tx++) ft.push_back(make_int4(l, tx, ty, 0));
+        if (!ft.empty()) HIP_TRY(ctx, hipMemcpy(base + off_ft, ft.data(), sizeof(int4) * ft.size(), hipMemcpyHostToDevice));
+        od.fast_tiles = (const int4*)(base + off_ft);
+        od.tpf_magic = tile_base > 1 ? (uint32_t)((1ull << 32) / (uint64_t)tile_base + 1) : 0u;
+    }
     std::vector<int4> tab;
     std::vector<std::vector<int2>> h_xt((size_t)L);
     std::vector<std::vector<int4>> h_yt((size_t)L);
