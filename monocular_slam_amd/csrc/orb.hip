@@ -800,6 +800,48 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x)
     return a;
 }
 
+// Row pass of the 7x7 Gaussian for one alignment XO of the patch inside its dword-aligned LDS rows.  The four output columns
+// of an item read source bytes XO + k .. XO + k + 6 of the 16 the item's four dwords hold; instead of shifting the bytes
+// into place (nine v_alignbyte per row) the taps are shifted: weight dword m of output k holds g[4 m + b - (XO + k)] in byte
+// b (zero outside 0..6), which leaves two or three v_dot4 per output -- ten per row for every XO, and no byte shuffles.
+__host__ __device__ constexpr uint32_t blur_w(int xo, int k, int m)
+{
+    constexpr int g[7] = { 18, 34, 49, 55, 49, 34, 18 };
+    uint32_t w = 0;
+    for (int b = 0; b < 4; b++) {
+        const int j = 4 * m + b - (xo + k);
+        if (j >= 0 && j <= 6) w |= (uint32_t)g[j] << (8 * b);
+    }
+    return w;
+}
+
+template <int XO>
+__device__ __forceinline__ void blur_rows(const uint32_t* __restrict__ raw32, uint32_t* __restrict__ hT, int lane)
+{
+    int rp = lane / DH_CG, cg = lane - rp * DH_CG; // item = rp * DH_CG + cg advances by 64 = 6 * DH_CG + 4
+    for (int i = lane; i < DH_RP * DH_CG; i += 64, rp += 6, cg += 4) {
+        if (cg >= DH_CG) { cg -= DH_CG; rp++; }
+        uint32_t h[2][4];
+#pragma unroll
+        for (int dr = 0; dr < 2; dr++) {
+            const uint32_t* q = raw32 + (2 * rp + dr) * (DP_PITCH / 4) + cg;
+            const uint32_t d[4] = { q[0], q[1], q[2], q[3] };
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                uint32_t acc = 0;
+#pragma unroll
+                for (int m = 0; m < 4; m++) {
+                    const uint32_t w = blur_w(XO, k, m);
+                    if (w) acc = __builtin_amdgcn_udot4(d[m], w, acc, false);   // (resolved at compile time: w is a constant)
+                }
+                h[dr][k] = acc; // <= 65535
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) hT[(4 * cg + k) * HT_DW + rp] = h[0][k] | (h[1][k] << 16);
+    }
+}
+
 struct DescArgs {
     mslam_keypoint* kps; uint8_t* desc; int32_t* n_out; int32_t* status; int cap;
 };
@@ -873,34 +915,17 @@ void describe_k(OrbDev od, DescArgs out)
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { m10 += __shfl_xor(m10, o); m01 += __shfl_xor(m01, o); }
     const float angle = fast_atan2_deg((float)m01, (float)m10);
-    // ---- separable 7x7 Gaussian of the patch with packed dot products (integer arithmetic: any association is exact).
-    // Rows: one item = 2 patch rows x 4 output columns; v_dot4_u32_u8 against the taps {18,34,49,55 | 49,34,18,0};
-    // the result is stored transposed (hT[col][row], u16) so that the column pass finds vertical neighbours packed
-    // in one dword for v_dot2_u32_u16.  Columns: one item = 1 column x 4 output rows, stored transposed as well
-    // (blurT[col][row], u8).  Rows/columns beyond 37 are scratch (computed from whatever LDS holds, never read back).
+    // ---- 7x7 Gaussian of the patch with packed dot products (integer arithmetic: any association is exact).
+    // Rows: one item = 2 patch rows x 4 output columns by v_dot4_u32_u8 (blur_rows, one instantiation per byte alignment of the
+    // patch); the result is stored transposed (hT[col][row], u16) so that the column taps of a pixel are vertical neighbours
+    // packed in consecutive dwords for v_dot2_u32_u16.  Rows/columns beyond 37 are scratch (computed from whatever LDS holds,
+    // never read back).
     uint32_t* hT = s_h[wave];
-    {
-        const uint32_t GA = 18u | (34u << 8) | (49u << 16) | (55u << 24), GB = 49u | (34u << 8) | (18u << 16);
-        int rp = lane / DH_CG, cg = lane - rp * DH_CG; // item = rp * DH_CG + cg advances by 64 = 6 * DH_CG + 4
-        for (int i = lane; i < DH_RP * DH_CG; i += 64, rp += 6, cg += 4) {
-            if (cg >= DH_CG) { cg -= DH_CG; rp++; }
-            uint32_t h[2][4];
-#pragma unroll
-            for (int dr = 0; dr < 2; dr++) {
-                const uint32_t* q = raw32 + (2 * rp + dr) * (DP_PITCH / 4) + cg;
-                const uint32_t d0 = q[0], d1 = q[1], d2 = q[2], d3 = q[3];
-                const uint32_t e0 = __builtin_amdgcn_alignbyte(d1, d0, xo), e1 = __builtin_amdgcn_alignbyte(d2, d1, xo),
-                               e2 = __builtin_amdgcn_alignbyte(d3, d2, xo);
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const uint32_t A = k ? __builtin_amdgcn_alignbyte(e1, e0, k) : e0;
-                    const uint32_t Bv = k ? __builtin_amdgcn_alignbyte(e2, e1, k) : e1;
-                    h[dr][k] = __builtin_amdgcn_udot4(Bv, GB, __builtin_amdgcn_udot4(A, GA, 0u, false), false); // <= 65535
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < 4; k++) hT[(4 * cg + k) * HT_DW + rp] = h[0][k] | (h[1][k] << 16);
-        }
+    switch (xo) {   // wave-uniform
+    case 0: blur_rows<0>(raw32, hT, lane); break;
+    case 1: blur_rows<1>(raw32, hT, lane); break;
+    case 2: blur_rows<2>(raw32, hT, lane); break;
+    default: blur_rows<3>(raw32, hT, lane); break;
     }
     __syncthreads();
     // ---- 256 rotated binary tests; test t = j*64 + lane, ballot j = descriptor bytes 8j..8j+7
