@@ -13,16 +13,17 @@
 // Kernel 2 (knn2_finalize): one workgroup per frame merges the per-chunk top-2 in chunk
 //   order, writes idx/dist, applies the float ratio test and compacts the survivors in
 //   query order with a ballot/prefix scan (deterministic, no atomics).
-// MFMA form (default; MSLAM_MATCH_MFMA=0 selects the kernel above): with every descriptor bit b stored as the int8 value
-//   2b - 1, the dot product of two descriptors is (#equal bits - #different bits) = 256 - 2 * Hamming, so the 2000 x 2000
+// MFMA form (default; MSLAM_MATCH_MFMA=0 selects the kernel above): with every descriptor bit b stored as an int8 value
+//   +-v, the dot product of two descriptors is v^2 (#equal bits - #different bits) = v^2 (256 - 2 * Hamming), so the 2000 x 2000
 //   distance table of a frame pair is an int8 Gram matrix and v_mfma_i32_32x32x32_i8 produces it exactly.  The tracking
 //   path as a whole is bound by VALU issue: this moves the xor/popcount work (16 of the 19 VALU
 //   instructions per pair and lane) onto the otherwise idle matrix pipe and leaves the top-2 bookkeeping on the VALU.
 //   expand_pm1_k writes the +-1 bytes in MFMA operand order (tile of 32 descriptors x k-step of 32 bits = 64 lanes x 16 B),
 //   so every operand load is one lane-linear 1 KiB read; hamming_mfma_k keeps 64 query columns per wavefront in registers
 //   (B operands), stages the train tiles through LDS (double-buffered, shared by the workgroup's two wavefronts) and folds
-//   each 32 x 32 tile into per-lane (best, second) keys.  The query side is stored negated and the accumulator starts at
-//   256, so a tile element IS 256 - dot = 2 * Hamming and a key is one v_lshl_add: (element << 16) + row.
+//   each 32 x 32 tile into per-lane (best, second) keys.  The bytes are +-127 with the query side negated and the accumulator
+//   starts at 127^2 * 256 + row, so a tile element IS the key 127^2 * 2 * Hamming + row (distance major, train index minor):
+//   per element only v_min + v_med3 remain.  Train indices must stay below 127^2 = 16129; larger sets take the VALU form.
 #include "common.h"
 
 namespace {
@@ -109,7 +110,7 @@ void expand_pm1_k(const uint8_t* __restrict__ q, const int32_t* __restrict__ nq_
     const int b = train ? blockIdx.z - B : blockIdx.z, s = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
     const int n = train ? nt_arr[b] : nq_arr[b];
     if (i >= ((n + 31) & ~31)) return;
-    const uint32_t flip = train ? 0xFFFFFFFFu : 0x01010101u;   // bit -> 0x01 / 0xFF (+1 / -1), or the negated pair
+    const uint32_t flip = train ? 0x81818181u : 0x7F7F7F7Fu;   // bit -> 0x7F / 0x81 (+127 / -127), or the negated pair
     uint32_t w = 0;
     const bool live = i < n;
     if (live) w = reinterpret_cast<const uint32_t*>((train ? t : q) + ((size_t)b * cap + i) * 32)[s];
@@ -127,12 +128,13 @@ void expand_pm1_k(const uint8_t* __restrict__ q, const int32_t* __restrict__ nq_
     }
 }
 
+constexpr int MF_SCALE = 127 * 127;      // a tile element is MF_SCALE * 2 * Hamming + row: train indices must stay below it
 template <bool MASK>
-__device__ __forceinline__ void fold_tile(const v16i& acc, const int (&c)[16], int limit, uint32_t& best, uint32_t& second)
+__device__ __forceinline__ void fold_tile(const v16i& acc, const v16i& c, int limit, uint32_t& best, uint32_t& second)
 {
 #pragma unroll
     for (int i = 0; i < 16; i++) {
-        uint32_t key = ((uint32_t)acc[i] << 16) + (uint32_t)c[i];   // 2 * Hamming << 16 | row
+        uint32_t key = (uint32_t)acc[i];   // the MFMA's own output is the key: no vector instruction to form it
         if (MASK) key = c[i] < limit ? key : KEY_NONE;
         top2_update(best, second, key);
     }
@@ -173,13 +175,12 @@ void hamming_mfma_k(const uint4* __restrict__ Eq, const int32_t* __restrict__ nq
         }
     }
     // row (train index within the tile) of accumulator element i of this lane: 8 (i / 4) + 4 (lane / 32) + i % 4
-    int c[16];
+    // The accumulator starts at MF_SCALE * 256 + row and the operand bytes are +-127 (query side negated), so an element
+    // comes out as MF_SCALE * (256 - dot) + row = MF_SCALE * 2 * Hamming + row: already the key (distance major, row minor).
+    v16i c;
 #pragma unroll
-    for (int i = 0; i < 16; i++) c[i] = 32 * t_lo + 8 * (i >> 2) + 4 * (lane >> 5) + (i & 3);
-    const int limit = nt;
-    v16i c256;
-#pragma unroll
-    for (int i = 0; i < 16; i++) c256[i] = 256;
+    for (int i = 0; i < 16; i++) c[i] = MF_SCALE * 256 + 32 * t_lo + 8 * (i >> 2) + 4 * (lane >> 5) + (i & 3);
+    const int limit = MF_SCALE * 256 + nt;
     uint32_t best[2] = { KEY_NONE, KEY_NONE }, second[2] = { KEY_NONE, KEY_NONE };
     if (nT > 0) {
 #pragma unroll
@@ -193,7 +194,7 @@ void hamming_mfma_k(const uint4* __restrict__ Eq, const int32_t* __restrict__ nq
         const uint4* nx = et + ((size_t)(more ? t + 1 : t) * 8 + wave * 4) * 64 + lane;
         const uint4 p0 = nx[0], p1 = nx[64], p2 = nx[128], p3 = nx[192];
         const uint4* tile = s_tile[t & 1];
-        v16i acc0 = c256, acc1 = c256;   // 256 + (train . -query) = 2 * Hamming
+        v16i acc0 = c, acc1 = c;
 #pragma unroll
         for (int s = 0; s < 8; s++) {
             const uint4 v = tile[s * 64 + lane];
@@ -211,7 +212,7 @@ void hamming_mfma_k(const uint4* __restrict__ Eq, const int32_t* __restrict__ nq
         uint4* nb = s_tile[(t + 1) & 1] + wave * 4 * 64 + lane;
         nb[0] = p0; nb[64] = p1; nb[128] = p2; nb[192] = p3;
 #pragma unroll
-        for (int i = 0; i < 16; i++) c[i] += 32;
+        for (int i = 0; i < 16; i++) c[i] += 32;   // next tile's rows
         __syncthreads();
     }
     // lanes l and l ^ 32 hold the same query column (different rows): merge, then the lower half writes
@@ -221,9 +222,10 @@ void hamming_mfma_k(const uint4* __restrict__ Eq, const int32_t* __restrict__ nq
         top2_update(best[blk], second[blk], ob);
         top2_update(best[blk], second[blk], os);
         const int qi = q0 + blk * 32 + (lane & 31);
-        // keys carry 2 * Hamming: back to (Hamming << 16 | row), the form knn2_finalize reads
-        const uint32_t kb = best[blk] == KEY_NONE ? KEY_NONE : ((best[blk] >> 17) << 16) | (best[blk] & 0xFFFFu);
-        const uint32_t ks = second[blk] == KEY_NONE ? KEY_NONE : ((second[blk] >> 17) << 16) | (second[blk] & 0xFFFFu);
+        // keys are MF_SCALE * 2 * Hamming + row: back to (Hamming << 16 | row), the form knn2_finalize reads
+        const uint32_t hb = best[blk] / (uint32_t)MF_SCALE, hs = second[blk] / (uint32_t)MF_SCALE;
+        const uint32_t kb = best[blk] == KEY_NONE ? KEY_NONE : ((hb >> 1) << 16) | (best[blk] - hb * (uint32_t)MF_SCALE);
+        const uint32_t ks = second[blk] == KEY_NONE ? KEY_NONE : ((hs >> 1) << 16) | (second[blk] - hs * (uint32_t)MF_SCALE);
         if (lane < 32 && qi < nq) part[((size_t)b * nsplit + by) * cap + qi] = make_uint2(kb, ks);
     }
 }
@@ -298,7 +300,7 @@ int mslam_match_knn2_batch_dev(mslam_ctx* ctx, const uint8_t* q, const int32_t* 
     MSLAM_TRY(ctx_set_device(ctx));
     static const int use_mfma = [] { const char* e = getenv("MSLAM_MATCH_MFMA"); return e ? atoi(e) : 1; }();
     void* scr = nullptr;
-    if (use_mfma) {
+    if (use_mfma && cap < MF_SCALE) {   // (train indices live below MF_SCALE in the keys; larger capacities take the VALU form)
         const int tiles_cap = (cap + 31) / 32;
         static const int nsplit = [] { const char* e = getenv("MSLAM_MATCH_SPLIT"); const int v = e ? atoi(e) : 4; return v < 1 ? 1 : (v > 16 ? 16 : v); }();
         const size_t e_bytes = align_up((size_t)B * tiles_cap * 8192, 256), p_bytes = align_up(sizeof(uint2) * (size_t)B * nsplit * cap, 256);

@@ -37,11 +37,12 @@ def test_ragged_sizes(ctx, oracle, nq, nt):
     _check(ctx, oracle, q, t)
 
 
-@pytest.mark.parametrize("nq,nt", [(31, 33), (32, 32), (33, 31), (127, 129), (128, 128), (129, 96), (2000, 95), (95, 2000), (1999, 2017), (65, 4095), (9000, 10000)])
+@pytest.mark.parametrize("nq,nt", [(31, 33), (32, 32), (33, 31), (127, 129), (128, 128), (129, 96), (2000, 95), (95, 2000), (1999, 2017), (65, 4095), (9000, 10000), (300, 16128), (300, 16200)])
 def test_sizes_around_the_mfma_tiles(ctx, oracle, nq, nt):
     """The matcher works on tiles of 32 train rows x 64 query columns per wavefront and cuts the train tiles into shares
     (hamming_mfma_k): sizes one off the tile, wavefront and workgroup boundaries, shares with no tile at all (nt = 95 with 4
-    shares of 1 tile), and rows of all-zero / all-one bits (dot products at both ends of the int8 range)."""
+    shares of 1 tile), rows of all-zero / all-one bits (dot products at both ends of the int8 range), and the largest train set
+    whose indices fit beside the distance in the MFMA's keys (16128 rows) next to one that takes the VALU form (16200)."""
     rng = np.random.default_rng(nq * 104729 + nt)
     q = rng.integers(0, 256, size=(nq, 32), dtype=np.uint8)
     t = rng.integers(0, 256, size=(nt, 32), dtype=np.uint8)
