@@ -369,8 +369,14 @@ void ba_schur_tiles_k(BaDev d)
         double acc[36];
 #pragma unroll
         for (int q = 0; q < 36; q++) acc[q] = 0.0;
+        // the block index of this thread's staging slot is fetched one group ahead (G * L <= SCHUR_GL < 256: one slot per thread),
+        // so that a group pays one exposed memory latency (the block itself), not two in a row
+        int k_next = -1;
+        { const int gc0 = min(G, np); if (tid < gc0 * L) { const int lq = tid / gc0, pi = tid - lq * gc0; k_next = tb[pi * L + lq]; } }
         for (int g0 = 0; g0 < np; g0 += G) {
             const int gc = min(G, np - g0);
+            const int k_cur = k_next;
+            { const int g1 = g0 + G, gc1 = min(G, np - g1); if (g1 < np && tid < gc1 * L) { const int lq = tid / gc1, pi = tid - lq * gc1; k_next = tb[(g1 + pi) * L + lq]; } }
             __syncthreads();   // the previous group's readers are done
             for (int it = tid; it < gc * L; it += 256) {
                 // one thread per block; consecutive lanes take consecutive points of one local pose: their blocks are neighbours
@@ -378,7 +384,7 @@ void ba_schur_tiles_k(BaDev d)
                 // threads and forming B Dinv in a second step was slower again, 0.34 ms)
                 const int lq = it / gc, pi = it - lq * gc;
                 const int idx = pi * L + lq;
-                const int k = tb[(g0 + pi) * L + lq];
+                const int k = k_cur;
                 double* sb = s_B + idx * SB_PITCH; double* sbd = s_BD + idx * SB_PITCH;
                 sb[18] = k >= 0 ? 1.0 : 0.0;
                 if (k >= 0) {
