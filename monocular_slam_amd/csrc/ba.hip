@@ -459,7 +459,16 @@ void ba_schur_final_k(BaDev d)
         int g = 0, e = 0;
         if (t < n_el) {
             g = (int)(t / 36); e = (int)(t % 36);
-            for (int q = d.gpair_ptr[g] + r; q < d.gpair_ptr[g + 1]; q += FIN_SPLIT) sum += d.tile_part[(size_t)d.gpair_src[q] * 36 + e];   // tile order
+            // (four partials per step: their index and value loads are independent, so they are in flight together)
+            const int q1 = d.gpair_ptr[g + 1];
+            int q = d.gpair_ptr[g] + r;
+            for (; q + 3 * FIN_SPLIT < q1; q += 4 * FIN_SPLIT) {
+                const int s0 = d.gpair_src[q], s1 = d.gpair_src[q + FIN_SPLIT], s2 = d.gpair_src[q + 2 * FIN_SPLIT], s3 = d.gpair_src[q + 3 * FIN_SPLIT];
+                const double v0 = d.tile_part[(size_t)s0 * 36 + e], v1 = d.tile_part[(size_t)s1 * 36 + e], v2 = d.tile_part[(size_t)s2 * 36 + e],
+                             v3 = d.tile_part[(size_t)s3 * 36 + e];
+                sum += v0; sum += v1; sum += v2; sum += v3;   // same order as one at a time
+            }
+            for (; q < q1; q += FIN_SPLIT) sum += d.tile_part[(size_t)d.gpair_src[q] * 36 + e];   // tile order
         }
 #pragma unroll
         for (int o = FIN_SPLIT / 2; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
@@ -473,13 +482,30 @@ void ba_schur_final_k(BaDev d)
         }
     }
     // b_s = b_p - sum_i B_ji (Dinv b_l)_i: the tile shares stored beside the diagonal pairs, in tile order
-    for (int t = blockIdx.x * 256 + threadIdx.x; t < np6; t += gridDim.x * 256) {
-        const int j = t / 6, a = t % 6;
-        const int g = d.gdiag[j];
+    // (FIN_SPLIT lanes per element like the blocks above, four partials in flight per lane: one lane walking all the tiles of a
+    // pose with two dependent loads per tile was the longest chain of the kernel)
+    const long long n_bs = ((long long)np6 * FIN_SPLIT + 255) / 256 * 256;
+    for (long long t0 = (long long)blockIdx.x * 256 + threadIdx.x; t0 < n_bs; t0 += (long long)gridDim.x * 256) {
+        const int t = (int)(t0 / FIN_SPLIT), r = (int)(t0 % FIN_SPLIT);
         double sum = 0.0;
-        if (g >= 0)
-            for (int q = d.gpair_ptr[g]; q < d.gpair_ptr[g + 1]; q++) sum += d.tile_coef[(size_t)d.gpair_src[q] * 6 + a];
-        d.bs[t] = d.b[t] - sum;
+        if (t < np6) {
+            const int j = t / 6, a = t % 6;
+            const int g = d.gdiag[j];
+            if (g >= 0) {
+                const int q1 = d.gpair_ptr[g + 1];
+                int q = d.gpair_ptr[g] + r;
+                for (; q + 3 * FIN_SPLIT < q1; q += 4 * FIN_SPLIT) {
+                    const int s0 = d.gpair_src[q], s1 = d.gpair_src[q + FIN_SPLIT], s2 = d.gpair_src[q + 2 * FIN_SPLIT], s3 = d.gpair_src[q + 3 * FIN_SPLIT];
+                    const double v0 = d.tile_coef[(size_t)s0 * 6 + a], v1 = d.tile_coef[(size_t)s1 * 6 + a], v2 = d.tile_coef[(size_t)s2 * 6 + a],
+                                 v3 = d.tile_coef[(size_t)s3 * 6 + a];
+                    sum += v0; sum += v1; sum += v2; sum += v3;
+                }
+                for (; q < q1; q += FIN_SPLIT) sum += d.tile_coef[(size_t)d.gpair_src[q] * 6 + a];
+            }
+        }
+#pragma unroll
+        for (int o = FIN_SPLIT / 2; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+        if (t < np6 && r == 0) d.bs[t] = d.b[t] - sum;
     }
 }
 
