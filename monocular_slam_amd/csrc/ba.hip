@@ -25,11 +25,12 @@
 //                butterfly + 4 wavefront partials into the chunk's partial
 //   ba_points_k  one lane per point: adds its edges' ptside rows in row order -> Hll, b_l, robust chi2 of the point
 //   ba_final_k   adds the chunk partials per pose in chunk order, reduces the robust chi2
-// Schur complement (tiles of SCHUR_TP consecutive points; a tile's pose list and its dense point x local-pose block table
+// Schur complement (tiles of at most SCHUR_TP consecutive points, ending at the seams of the pose graph; a tile's pose list and its dense point x local-pose block table
 // are plan data, O(points x poses-per-tile) instead of the dense poses x points table):
 //   ba_schur_points_k  (Hll + lambda I)^-1 and its product with b_l, per point
-//   ba_schur_tiles_k   per tile: blocks staged once through LDS with B Dinv formed on the way; per local pose pair the sum
-//                      over the tile's points of (B Dinv)_j1 B_j2^T in registers; per local pose the sum of B (Dinv b_l)
+//   ba_schur_tiles_k   per tile: each wavefront takes every fourth point, its blocks prefetched into registers and staged through
+//                      the wavefront's own LDS with B Dinv formed on the way; per local pose pair the sum over the points of
+//                      (B Dinv)_j1 B_j2^T in registers; per local pose the sum of B (Dinv b_l)
 //   ba_schur_final_k   S block (j1, j2) = [Hpp + lambda I] - sum of the tile partials in tile order; b_s
 //   ba_backsub_k / ba_window_sums_k   x_l, X += x_l, and the per-window sums of LM's computeScale and chi2
 // lambda may differ per WINDOW (mslam_ba_plan_set_windows): block-diagonal batches of independent local-BA windows then
@@ -49,8 +50,8 @@ namespace {
 constexpr int EDGE_CHUNK = 256;    // edges per ba_edges_k workgroup
 constexpr int T_PITCH = 258;       // LDS plane pitch (doubles) of the block transpose: 258 = 2 (mod 32) spreads the planes over banks
 constexpr int SCHUR_TP = 64;       // points per Schur tile
-constexpr int SCHUR_NSUB = 4;      // point subsets per (tile, pair): adjacent lanes, summed by a 2-step butterfly
 constexpr int SCHUR_LMAX = 64;     // local poses per tile beyond which the device Schur path is not offered
+constexpr int SCHUR_DD = 12;       // doubles of the packed per-point record a Schur tile reads: Dinv (9), Dinv b_l (3) = 6 pieces of 16 bytes
 
 struct BaDev {
     int n_poses, n_points, n_edges, n_free, nnzb, n_rows, n_chunks_max;
@@ -73,14 +74,15 @@ struct BaDev {
     const int32_t* col;       // [nnzb] point of a block
     int n_tiles; long long n_tile_pairs;
     const int32_t* tile_pose_ptr; const int32_t* tile_pose;   // local pose list of a tile (free row ids, ascending)
-    const int32_t* tile_blk_ptr;  const int32_t* tile_blk;    // [tile][SCHUR_TP][L] block of (point, local pose) or -1
+    const int32_t* tile_pt0;                                  // [n_tiles + 1] first point of a tile (at most SCHUR_TP points each)
+    const int32_t* tile_blk_ptr;  const int32_t* tile_blk;    // [tile][points of the tile][L] block of (point, local pose) or -1
     const long long* tile_out_ptr;                            // first partial (36 doubles each) of a tile
     int n_gpairs; const int32_t* gpair_j; const int32_t* gpair_ptr; const long long* gpair_src; // global pose pairs and their partials
     const int32_t* gdiag;     // [n_free] global pair index of (j, j) or -1
     double* tile_part;        // [n_tile_pairs][36]
     double* tile_coef;        // [n_tile_pairs][6] (diagonal local pairs only)
     double* Dinv;             // [n_points][9]  (Hll + lambda I)^-1
-    double* db;               // [n_points][3]  Dinv b_l
+    double* DD;               // [n_points][12] {Dinv, Dinv b_l} packed: what a Schur tile reads per point
     double* S;                // [6 n_free][6 n_free]
     double* bs;               // [6 n_free]
     double* x;                // [6 n_free + 3 n_points]
@@ -331,117 +333,186 @@ void ba_schur_points_k(BaDev d)
     const double* bl = d.b + 6 * d.n_free + 3 * (size_t)i;
 #pragma unroll
     for (int q = 0; q < 9; q++) d.Dinv[(size_t)i * 9 + q] = I[q];
+    double* dd = d.DD + (size_t)i * SCHUR_DD;
 #pragma unroll
-    for (int a = 0; a < 3; a++) d.db[(size_t)i * 3 + a] = I[a * 3] * bl[0] + I[a * 3 + 1] * bl[1] + I[a * 3 + 2] * bl[2];
+    for (int q = 0; q < 9; q++) dd[q] = I[q];
+#pragma unroll
+    for (int a = 0; a < 3; a++) dd[9 + a] = I[a * 3] * bl[0] + I[a * 3 + 1] * bl[1] + I[a * 3 + 2] * bl[2];
 }
 
-// One workgroup per tile of SCHUR_TP consecutive points; the tile's blocks are read from HBM exactly once.  Points are
-// taken in groups of G (G * L <= SCHUR_GL): a thread stages one block B (6x3) of the group into LDS together with
-// B Dinv (computed on the way: Dinv is 3x3 per point) and a validity flag; then item (local pose pair (la <= lb), subset s)
-// adds (B Dinv)_{la} B_{lb}^T over its share of the group's points into 36 registers (g2o's own loop shape,
-// block_solver.hpp:381-432, with the point loop innermost).  The SCHUR_NSUB subsets of a pair sit in adjacent lanes and are
-// added by a 2-step butterfly at the end.  Lanes la < L also accumulate B (Dinv b_l): the tile's share of the reduced
-// right-hand side's coefficient, stored beside the diagonal pair (la, la).
-constexpr int SCHUR_GL = 96;       // (points x local poses) staged per group
-constexpr int SB_PITCH = 19;       // doubles per staged block: 18 values + validity; odd -> lanes spread over the LDS banks
+// piece 64 r + ln of point pi of a Schur tile: a 16-byte part of one of its blocks (missing block: block 0, never used) or of its
+// packed record
+template <int R> struct SchurPieces { typedef double type __attribute__((ext_vector_type(2 * R))); };   // (a value, not an array: stays in registers)
+template <int R>
+__device__ __forceinline__ typename SchurPieces<R>::type schur_fetch(const BaDev& d, const int32_t* s_tb, int L, int i0, int pi, int ln)
+{
+    typename SchurPieces<R>::type v;
+    const int npieces = 9 * L + 6;
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const int j = min(r * 64 + ln, npieces - 1);   // (lanes past the last piece repeat it)
+        const int lq = j / 9;
+        // branch-free: every lane issues exactly R loads per point, so the loads in flight are counted, not waited out
+        const int k = s_tb[pi * L + min(lq, L - 1)];
+        const double* sb = d.Hpl_val + (size_t)max(k, 0) * 18 + 2 * (j - 9 * lq);
+        const double* sd = d.DD + (size_t)(i0 + pi) * SCHUR_DD + 2 * (j - 9 * L);
+        const double2 t = *reinterpret_cast<const double2*>(lq < L ? sb : sd);
+        v[2 * r] = t.x; v[2 * r + 1] = t.y;
+    }
+    return v;
+}
+
+// One workgroup per tile of at most SCHUR_TP consecutive points, four wavefronts that never meet inside the point loop: wavefront w
+// takes the points w, w + 4, ... of the tile, one at a time, with lane = local pose pair (la <= lb).  A point's data -- its
+// <= L blocks B (6x3, 144 bytes each) and its packed {Dinv, Dinv b_l} (96 bytes) -- are "pieces" of 16 bytes: lane j of load
+// instruction r fetches piece 64 r + j into registers THREE points ahead of its use (the block indices come from the tile's table,
+// copied to LDS once), writes it to the wavefront's own LDS stage when its turn comes, and the wavefront then forms B Dinv
+// (one lane per block row) and, per pair, adds (B Dinv)_{la} B_{lb}^T into 36 registers (g2o's own loop shape,
+// block_solver.hpp:381-432, with the point loop innermost).  The LDS traffic of one wavefront is ordered by program order, so no
+// workgroup barrier sits between a point's loads and its use: the memory latency is covered by the three points in flight and by
+// the other wavefronts.  Lanes j < 6 L also accumulate row j of B (Dinv b_l): the tile's share of the reduced right-hand
+// side's coefficient, stored beside the diagonal pair (la, la).  The four wavefronts' sums are added as (0 + 2) + (1 + 3).
+// R = load instructions per point: 9 L + 6 <= 64 R.
+template <int R>
 __global__ __launch_bounds__(256)
 void ba_schur_tiles_k(BaDev d)
 {
-    __shared__ double s_B[SCHUR_GL * SB_PITCH], s_BD[SCHUR_GL * SB_PITCH];
-    __shared__ double s_cb[SCHUR_GL * 6];      // B (Dinv b_l) of the staged blocks
-    __shared__ double s_coef[SCHUR_LMAX * 6];  // running coefficient sums per local pose
-    const int tile = blockIdx.x, tid = threadIdx.x;
+    constexpr int SLOT = R * 128;                       // doubles of one stage: R x 64 pieces
+    constexpr int MAIN = 8 * SLOT > 2 * 64 * 36 ? 8 * SLOT : 2 * 64 * 36;   // 4 wavefronts x {stage, B Dinv}; later the cross-wavefront sum
+    constexpr int LCAP = (64 * R - 6) / 9;              // local poses this instantiation can stage
+    constexpr int CR = (6 * LCAP + 63) / 64;            // block rows per lane
+    extern __shared__ double s_dyn[];
+    int32_t* const s_tb = reinterpret_cast<int32_t*>(s_dyn + MAIN);   // [SCHUR_TP][L] block index table of the tile
+    const int tile = blockIdx.x, tid = threadIdx.x, w = tid >> 6, ln = tid & 63;
     const int L = d.tile_pose_ptr[tile + 1] - d.tile_pose_ptr[tile];
     if (L == 0) return;
     const int npairs = L * (L + 1) / 2;
     const int32_t* tb = d.tile_blk + d.tile_blk_ptr[tile];
-    const int i0 = tile * SCHUR_TP, np = min(SCHUR_TP, d.n_points - i0);
+    const int i0 = d.tile_pt0[tile], np = d.tile_pt0[tile + 1] - i0;
     double* out = d.tile_part + (size_t)d.tile_out_ptr[tile] * 36;
     double* cout = d.tile_coef + (size_t)d.tile_out_ptr[tile] * 6;
-    const int G = max(1, SCHUR_GL / L);
-    const int s = tid & (SCHUR_NSUB - 1);
-    const int npass = (npairs * SCHUR_NSUB + 255) / 256;       // pair passes (1 for L <= 10); wider tiles re-stage per pass
-    for (int idx = tid; idx < L * 6; idx += 256) s_coef[idx] = 0.0;
+    double* const sB = s_dyn + w * 2 * SLOT;            // this wavefront's stage: blocks at 18 lq, the packed record at 18 L
+    double* const sBD = sB + SLOT;
+    for (int i = tid; i < np * L; i += 256) s_tb[i] = tb[i];
+    __syncthreads();
+    const int n_my = np > w ? (np - w + 3) >> 2 : 0;    // points of this wavefront
+    double coef[CR];
+#pragma unroll
+    for (int c = 0; c < CR; c++) coef[c] = 0.0;
+    const int npass = (npairs + 63) / 64;       // pair passes (1 for L <= 10); wider tiles run the point loop once per pass
     for (int pass = 0; pass < npass; pass++) {
-        const int p = tid / SCHUR_NSUB + pass * (256 / SCHUR_NSUB);
+        const int p = ln + pass * 64;
         int la = 0, lb = 0;
         if (p < npairs) { int rem = p; while (rem >= L - la) { rem -= L - la; la++; } lb = la + rem; }
         double acc[36];
 #pragma unroll
         for (int q = 0; q < 36; q++) acc[q] = 0.0;
-        // the block index of this thread's staging slot is fetched one group ahead (G * L <= SCHUR_GL < 256: one slot per thread),
-        // so that a group pays one exposed memory latency (the block itself), not two in a row
-        int k_next = -1;
-        { const int gc0 = min(G, np); if (tid < gc0 * L) { const int lq = tid / gc0, pi = tid - lq * gc0; k_next = tb[pi * L + lq]; } }
-        for (int g0 = 0; g0 < np; g0 += G) {
-            const int gc = min(G, np - g0);
-            const int k_cur = k_next;
-            { const int g1 = g0 + G, gc1 = min(G, np - g1); if (g1 < np && tid < gc1 * L) { const int lq = tid / gc1, pi = tid - lq * gc1; k_next = tb[(g1 + pi) * L + lq]; } }
-            __syncthreads();   // the previous group's readers are done
-            for (int it = tid; it < gc * L; it += 256) {
-                // one thread per block; consecutive lanes take consecutive points of one local pose: their blocks are neighbours
-                // in that pose's row (measured: 0.43 -> 0.24 ms against point-major lanes; moving 16-byte pieces with all
-                // threads and forming B Dinv in a second step was slower again, 0.34 ms)
-                const int lq = it / gc, pi = it - lq * gc;
-                const int idx = pi * L + lq;
-                const int k = k_cur;
-                double* sb = s_B + idx * SB_PITCH; double* sbd = s_BD + idx * SB_PITCH;
-                sb[18] = k >= 0 ? 1.0 : 0.0;
-                if (k >= 0) {
-                    const double2* src = reinterpret_cast<const double2*>(d.Hpl_val + (size_t)k * 18);
-                    const double* Di = d.Dinv + (size_t)(i0 + g0 + pi) * 9;
-                    const double* dbi = d.db + (size_t)(i0 + g0 + pi) * 3;
+        // pieces of the current point and of the next three.  The point loop is unrolled by four so that each of the four register
+        // sets keeps its role (a register copy would have to wait for the load it copies) and has ONE exit (an exit between two
+        // steps would merge "just loaded" into the loop header's state and bring the full wait back): a wavefront whose point count
+        // is no multiple of four runs the missing steps on its last point with nothing accumulated, and fetches past the last point
+        // repeat it (cached, unused), so that every step issues the same R loads
+        const int n_u = __builtin_amdgcn_readfirstlane(n_my);
+        const int pi_last = w + 4 * (n_u - 1);
+        typename SchurPieces<R>::type v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
+        auto step = [&](int it, const typename SchurPieces<R>::type& cur, typename SchurPieces<R>::type& fut) {
+            const int pi = min(w + 4 * it, pi_last);
+            fut = schur_fetch<R>(d, s_tb, L, i0, min(w + 4 * it + 12, pi_last), ln);
+            // which of the point's blocks exist (wave-uniform mask over the local poses; none in a padding step)
+            const unsigned long long vm = __builtin_amdgcn_ballot_w64(it < n_u && ln < L && s_tb[pi * L + ln] >= 0);
 #pragma unroll
-                    for (int q = 0; q < 9; q++) { const double2 v2 = src[q]; sb[2 * q] = v2.x; sb[2 * q + 1] = v2.y; }
-                    const double D0 = Di[0], D1 = Di[1], D2 = Di[2], D3 = Di[3], D4 = Di[4], D5 = Di[5], D6 = Di[6], D7 = Di[7], D8 = Di[8];
-                    const double e0 = dbi[0], e1 = dbi[1], e2 = dbi[2];
+            for (int r = 0; r < R; r++)   // (every lane: the slots past the last piece exist and receive its copy -- no branch around the wait for the load)
+                *reinterpret_cast<double2*>(sB + 2 * (r * 64 + ln)) = make_double2(cur[2 * r], cur[2 * r + 1]);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            {   // B Dinv and B (Dinv b_l), one block row per lane
+                const double* DD = sB + 18 * L;
+                const double D0 = DD[0], D1 = DD[1], D2 = DD[2], D3 = DD[3], D4 = DD[4], D5 = DD[5], D6 = DD[6], D7 = DD[7], D8 = DD[8];
+                const double e0 = DD[9], e1 = DD[10], e2 = DD[11];
 #pragma unroll
-                    for (int a = 0; a < 6; a++) {
-                        const double b0 = sb[a * 3], b1 = sb[a * 3 + 1], b2 = sb[a * 3 + 2];
-                        sbd[a * 3] = b0 * D0 + b1 * D3 + b2 * D6; sbd[a * 3 + 1] = b0 * D1 + b1 * D4 + b2 * D7; sbd[a * 3 + 2] = b0 * D2 + b1 * D5 + b2 * D8;
-                        if (pass == 0) s_cb[idx * 6 + a] = b0 * e0 + b1 * e1 + b2 * e2;
+                for (int c = 0; c < CR; c++) {
+                    const int j = c * 64 + ln;
+                    if (j < 6 * L) {
+                        const double b0 = sB[3 * j], b1 = sB[3 * j + 1], b2 = sB[3 * j + 2];
+                        sBD[3 * j] = b0 * D0 + b1 * D3 + b2 * D6; sBD[3 * j + 1] = b0 * D1 + b1 * D4 + b2 * D7; sBD[3 * j + 2] = b0 * D2 + b1 * D5 + b2 * D8;
+                        if (pass == 0 && ((vm >> (j / 6)) & 1ull)) coef[c] += b0 * e0 + b1 * e1 + b2 * e2;
                     }
                 }
             }
-            __syncthreads();
-            if (p < npairs)
-                for (int pi = s; pi < gc; pi += SCHUR_NSUB) {
-                    const double* a_ = s_BD + (pi * L + la) * SB_PITCH;
-                    const double* b_ = s_B + (pi * L + lb) * SB_PITCH;
-                    if (s_B[(pi * L + la) * SB_PITCH + 18] == 0.0 || b_[18] == 0.0) continue;
-                    double bb[18];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (p < npairs && ((vm >> la) & (vm >> lb) & 1ull)) {
+                const double2* a2 = reinterpret_cast<const double2*>(sBD + 18 * la);
+                const double2* b2 = reinterpret_cast<const double2*>(sB + 18 * lb);
+                double bb[18];
 #pragma unroll
-                    for (int q = 0; q < 18; q++) bb[q] = b_[q];
+                for (int q = 0; q < 9; q++) { const double2 t = b2[q]; bb[2 * q] = t.x; bb[2 * q + 1] = t.y; }
 #pragma unroll
-                    for (int a = 0; a < 6; a++) {
-                        const double a0 = a_[a * 3], a1 = a_[a * 3 + 1], a2 = a_[a * 3 + 2];
+                for (int ap = 0; ap < 3; ap++) {   // two rows of B Dinv (three 16-byte reads) at a time
+                    const double2 t0 = a2[3 * ap], t1 = a2[3 * ap + 1], t2 = a2[3 * ap + 2];
+                    const double aa[6] = { t0.x, t0.y, t1.x, t1.y, t2.x, t2.y };
 #pragma unroll
-                        for (int c = 0; c < 6; c++) acc[a * 6 + c] += a0 * bb[c * 3] + a1 * bb[c * 3 + 1] + a2 * bb[c * 3 + 2];
-                    }
+                    for (int h = 0; h < 2; h++)
+#pragma unroll
+                        for (int c = 0; c < 6; c++)
+                            acc[(2 * ap + h) * 6 + c] += aa[3 * h] * bb[c * 3] + aa[3 * h + 1] * bb[c * 3 + 1] + aa[3 * h + 2] * bb[c * 3 + 2];
                 }
-            if (pass == 0 && tid < L * 6) {   // coefficient of local pose tid / 6, component tid % 6: the group's points in order
-                const int lq = tid / 6, a = tid - 6 * lq;
-                double t = s_coef[tid];
-                for (int pi = 0; pi < gc; pi++)
-                    if (s_B[(pi * L + lq) * SB_PITCH + 18] != 0.0) t += s_cb[(pi * L + lq) * 6 + a];
-                s_coef[tid] = t;
+            }
+            __builtin_amdgcn_wave_barrier();   // (the next point's stage writes stay behind these reads)
+        };
+        if (n_u > 0) {
+            v0 = schur_fetch<R>(d, s_tb, L, i0, w, ln);
+            v1 = schur_fetch<R>(d, s_tb, L, i0, min(w + 4, pi_last), ln);
+            v2 = schur_fetch<R>(d, s_tb, L, i0, min(w + 8, pi_last), ln);
+            for (int it = 0; it < n_u; it += 4) {
+                step(it, v0, v3);
+                step(it + 1, v1, v0);
+                step(it + 2, v2, v1);
+                step(it + 3, v3, v2);
             }
         }
+        // wavefronts summed as (0 + 2) + (1 + 3), through the stage storage (element-major: consecutive lanes, consecutive doubles)
+        __syncthreads();   // every wavefront is done with its stage
+        if (w >= 2)
 #pragma unroll
-        for (int o = SCHUR_NSUB / 2; o > 0; o >>= 1)
+            for (int q = 0; q < 36; q++) s_dyn[((w - 2) * 36 + q) * 64 + ln] = acc[q];
+        __syncthreads();
+        if (w < 2)
 #pragma unroll
-            for (int q = 0; q < 36; q++) acc[q] += __shfl_xor(acc[q], o);
-        if (s == 0 && p < npairs)
+            for (int q = 0; q < 36; q++) acc[q] += s_dyn[(w * 36 + q) * 64 + ln];
+        __syncthreads();
+        if (w == 1)
 #pragma unroll
-            for (int q = 0; q < 36; q++) out[(size_t)p * 36 + q] = acc[q];
+            for (int q = 0; q < 36; q++) s_dyn[q * 64 + ln] = acc[q];
+        __syncthreads();
+        if (w == 0 && p < npairs)
+#pragma unroll
+            for (int q = 0; q < 36; q++) out[(size_t)p * 36 + q] = acc[q] + s_dyn[q * 64 + ln];
+        __syncthreads();   // (the next pass writes the stages again)
     }
+    // the coefficient rows, the same way
+    if (w >= 2)
+#pragma unroll
+        for (int c = 0; c < CR; c++) s_dyn[((w - 2) * CR + c) * 64 + ln] = coef[c];
     __syncthreads();
-    for (int idx = tid; idx < L * 6; idx += 256) {
-        const int lq = idx / 6;
-        int pd = 0;   // index of the diagonal pair (lq, lq) in the tile's upper-triangle order
-        for (int a = 0; a < lq; a++) pd += L - a;
-        cout[(size_t)pd * 6 + (idx - 6 * lq)] = s_coef[idx];
-    }
+    if (w < 2)
+#pragma unroll
+        for (int c = 0; c < CR; c++) coef[c] += s_dyn[(w * CR + c) * 64 + ln];
+    __syncthreads();
+    if (w == 1)
+#pragma unroll
+        for (int c = 0; c < CR; c++) s_dyn[c * 64 + ln] = coef[c];
+    __syncthreads();
+    if (w == 0)
+#pragma unroll
+        for (int c = 0; c < CR; c++) {
+            const int j = c * 64 + ln;
+            if (j < 6 * L) {
+                const int lq = j / 6;
+                const int pd = lq * L - lq * (lq - 1) / 2;   // index of the diagonal pair (lq, lq) in the tile's upper-triangle order
+                cout[(size_t)pd * 6 + (j - 6 * lq)] = coef[c] + s_dyn[c * 64 + ln];
+            }
+        }
 }
 
 // S (zeroed by the caller) <- one 6x6 block per global pose pair that shares a point; b_s
@@ -582,6 +653,7 @@ struct mslam_ba_plan {
     std::vector<int32_t> h_rowptr, h_col;
     std::vector<int32_t> h_row_pose;         // pose of a free row
     bool has_schur = false;
+    int schur_lmax = 0;       // widest Schur tile (local poses): selects ba_schur_tiles_k's instantiation
 };
 
 static int ba_validate(const mslam_ba_problem* p)
@@ -664,16 +736,40 @@ int mslam_ba_plan_create(mslam_ctx* ctx, const mslam_ba_problem* p, mslam_ba_pla
     const int n_chunks_max = std::max(1, (max_row + EDGE_CHUNK - 1) / EDGE_CHUNK);
 
     // ---- Schur tiles: local pose lists, dense point x local-pose block tables, partial offsets, global pair lists
-    const int n_tiles = (NL + SCHUR_TP - 1) / SCHUR_TP;
+    // Schur tiles: runs of at most SCHUR_TP consecutive points; a tile also ends where the next point belongs to another
+    // connected component of the pose graph (poses linked by a common point) -- the seam between two windows of a block-diagonal
+    // batch: a tile across it would carry both windows' poses, i.e. four times the pose pairs, for nothing
+    std::vector<int32_t> tile_pt0(1, 0);
+    {
+        std::vector<int32_t> parent(std::max(nf, 1));
+        for (int f = 0; f < nf; f++) parent[f] = f;
+        auto find = [&](int f) { while (parent[f] != f) { parent[f] = parent[parent[f]]; f = parent[f]; } return f; };
+        auto first_row = [&](int i) { for (int q = pt_ptr[i]; q < pt_ptr[i + 1]; q++) if (pt_k[q] < nnzb) return (int)blk_row[pt_k[q]]; return -1; };
+        for (int i = 0; i < NL; i++) {
+            const int r0 = first_row(i);
+            if (r0 < 0) continue;
+            for (int q = pt_ptr[i]; q < pt_ptr[i + 1]; q++) { const int k = pt_k[q]; if (k < nnzb) { const int a = find(r0), c = find(blk_row[k]); if (a != c) parent[c] = a; } }
+        }
+        int cnt = 0, comp = -1;   // points and component of the tile being filled
+        for (int i = 0; i < NL; i++) {
+            const int r0 = first_row(i), ci = r0 >= 0 ? find(r0) : -1;
+            if (cnt == SCHUR_TP || (cnt > 0 && ci >= 0 && comp >= 0 && ci != comp)) { tile_pt0.push_back(i); cnt = 0; comp = -1; }
+            if (ci >= 0) comp = ci;
+            cnt++;
+        }
+        tile_pt0.push_back(NL);
+    }
+    const int n_tiles = (int)tile_pt0.size() - 1;
     std::vector<int32_t> tile_pose_ptr(n_tiles + 1, 0), tile_pose, tile_blk_ptr(n_tiles + 1, 0), tile_blk;
     std::vector<long long> tile_out_ptr(n_tiles + 1, 0);
     bool want_schur = nf > 0 && nnzb > 0;
+    int schur_lmax = 0;
     std::vector<int32_t> gpair_j, gpair_ptr;
     std::vector<long long> gpair_src;
     if (want_schur) {
         std::vector<int32_t> loc(nf, -1);
         for (int t = 0; t < n_tiles && want_schur; t++) {
-            const int i0 = t * SCHUR_TP, i1 = std::min(NL, i0 + SCHUR_TP);
+            const int i0 = tile_pt0[t], i1 = tile_pt0[t + 1];
             std::vector<int32_t> lp;
             for (int i = i0; i < i1; i++)
                 for (int q = pt_ptr[i]; q < pt_ptr[i + 1]; q++) { const int k = pt_k[q]; if (k < nnzb) lp.push_back(blk_row[k]); }
@@ -681,9 +777,10 @@ int mslam_ba_plan_create(mslam_ctx* ctx, const mslam_ba_problem* p, mslam_ba_pla
             lp.erase(std::unique(lp.begin(), lp.end()), lp.end());
             const int L = (int)lp.size();
             if (L > SCHUR_LMAX) { want_schur = false; break; }   // a tile that sees too many poses: host Schur (MSLAM_ERR_CAPACITY)
+            schur_lmax = std::max(schur_lmax, L);
             for (int a = 0; a < L; a++) loc[lp[a]] = a;
             const size_t base = tile_blk.size();
-            tile_blk.resize(base + (size_t)SCHUR_TP * L, -1);
+            tile_blk.resize(base + (size_t)(i1 - i0) * L, -1);
             for (int i = i0; i < i1; i++)
                 for (int q = pt_ptr[i]; q < pt_ptr[i + 1]; q++) { const int k = pt_k[q]; if (k < nnzb) tile_blk[base + (size_t)(i - i0) * L + loc[blk_row[k]]] = k; }
             tile_pose.insert(tile_pose.end(), lp.begin(), lp.end());
@@ -734,16 +831,17 @@ int mslam_ba_plan_create(mslam_ctx* ctx, const mslam_ba_problem* p, mslam_ba_pla
                  o_ptr = reserve(sizeof(double) * NL), o_chp = reserve(sizeof(double) * ((size_t)NL / CHI_SLICE + 1)),
                  o_pp = reserve(sizeof(double) * 27 * (size_t)std::max(nf, 1) * n_chunks_max), o_rc = reserve(sizeof(double)),
                  o_lam = reserve(sizeof(double));
-    size_t o_tpp = 0, o_tp = 0, o_tbp = 0, o_tb = 0, o_top = 0, o_gj = 0, o_gp = 0, o_gs = 0, o_part = 0, o_dinv = 0, o_db = 0, o_gd = 0, o_tc = 0,
+    size_t o_tp0 = 0, o_tpp = 0, o_tp = 0, o_tbp = 0, o_tb = 0, o_top = 0, o_gj = 0, o_gp = 0, o_gs = 0, o_part = 0, o_dinv = 0, o_db = 0, o_gd = 0, o_tc = 0,
            o_S = 0, o_bs = 0, o_x = 0, o_bk = 0, o_psc = 0, o_sp = 0, o_sl = 0;
     if (want_schur) {
+        o_tp0 = reserve(sizeof(int32_t) * (n_tiles + 1));
         o_tpp = reserve(sizeof(int32_t) * (n_tiles + 1)); o_tp = reserve(sizeof(int32_t) * std::max<size_t>(tile_pose.size(), 1));
         o_tbp = reserve(sizeof(int32_t) * (n_tiles + 1)); o_tb = reserve(sizeof(int32_t) * std::max<size_t>(tile_blk.size(), 1));
         o_top = reserve(sizeof(long long) * (n_tiles + 1));
         o_gj = reserve(sizeof(int32_t) * 2 * std::max(n_gpairs, 1)); o_gp = reserve(sizeof(int32_t) * (n_gpairs + 1));
         o_gs = reserve(sizeof(long long) * std::max<size_t>(gpair_src.size(), 1));
         o_part = reserve(sizeof(double) * 36 * (size_t)std::max<long long>(tile_out_ptr[n_tiles], 1));
-        o_dinv = reserve(sizeof(double) * 9 * NL); o_db = reserve(sizeof(double) * 3 * NL);
+        o_dinv = reserve(sizeof(double) * 9 * NL); o_db = reserve(sizeof(double) * 12 * NL);
         o_gd = reserve(sizeof(int32_t) * std::max(nf, 1)); o_tc = reserve(sizeof(double) * 6 * (size_t)std::max<long long>(tile_out_ptr[n_tiles], 1));
         o_S = reserve(sizeof(double) * 36 * (size_t)nf * nf); o_bs = reserve(sizeof(double) * 6 * nf);
         o_x = reserve(sizeof(double) * (6 * nf + 3 * NL)); o_bk = reserve(sizeof(double) * 3 * NL);
@@ -763,6 +861,7 @@ int mslam_ba_plan_create(mslam_ctx* ctx, const mslam_ba_problem* p, mslam_ba_pla
         up(o_ptp, pt_ptr.data(), sizeof(int32_t) * (NL + 1)), up(o_ptk, pt_k.data(), sizeof(int32_t) * E),
         up(o_col, col.data(), sizeof(int32_t) * nnzb), up(o_brow, blk_row.data(), sizeof(int32_t) * nnzb), up(o_lam, &lam0, sizeof(double)) };
     if (want_schur) {
+        errs.push_back(up(o_tp0, tile_pt0.data(), sizeof(int32_t) * (n_tiles + 1)));
         errs.push_back(up(o_tpp, tile_pose_ptr.data(), sizeof(int32_t) * (n_tiles + 1)));
         errs.push_back(up(o_tp, tile_pose.data(), sizeof(int32_t) * tile_pose.size()));
         errs.push_back(up(o_tbp, tile_blk_ptr.data(), sizeof(int32_t) * (n_tiles + 1)));
@@ -797,14 +896,15 @@ int mslam_ba_plan_create(mslam_ctx* ctx, const mslam_ba_problem* p, mslam_ba_pla
     d.n_windows = 1; d.pose_win = nullptr; d.point_win = nullptr; d.win_pt_ptr = nullptr; d.win_pt = nullptr; d.lam_w = pl->d_lam; d.win_out = nullptr;
     if (want_schur) {
         d.n_tiles = n_tiles; d.n_tile_pairs = tile_out_ptr[n_tiles];
+        d.tile_pt0 = (int32_t*)(base + o_tp0);
         d.tile_pose_ptr = (int32_t*)(base + o_tpp); d.tile_pose = (int32_t*)(base + o_tp);
         d.tile_blk_ptr = (int32_t*)(base + o_tbp); d.tile_blk = (int32_t*)(base + o_tb); d.tile_out_ptr = (long long*)(base + o_top);
         d.n_gpairs = n_gpairs; d.gpair_j = (int32_t*)(base + o_gj); d.gpair_ptr = (int32_t*)(base + o_gp); d.gpair_src = (long long*)(base + o_gs);
         d.tile_part = (double*)(base + o_part);
-        d.Dinv = (double*)(base + o_dinv); d.db = (double*)(base + o_db); d.gdiag = (int32_t*)(base + o_gd); d.tile_coef = (double*)(base + o_tc);
+        d.Dinv = (double*)(base + o_dinv); d.DD = (double*)(base + o_db); d.gdiag = (int32_t*)(base + o_gd); d.tile_coef = (double*)(base + o_tc);
         d.S = (double*)(base + o_S); d.bs = (double*)(base + o_bs); d.x = (double*)(base + o_x); d.points_bk = (double*)(base + o_bk);
         d.pt_scale = (double*)(base + o_psc); d.scale_part = (double*)(base + o_sp); d.scale_l = (double*)(base + o_sl);
-        pl->has_schur = true;
+        pl->has_schur = true; pl->schur_lmax = schur_lmax;
     }
     *out = pl;
     return MSLAM_OK;
@@ -943,7 +1043,20 @@ static int schur_launch(mslam_ba_plan* pl)
     const size_t n6 = 6 * (size_t)d.n_free;
     HIP_TRY(ctx, hipMemsetAsync(d.S, 0, sizeof(double) * n6 * n6, ctx->stream));   // pose pairs that share no point
     LAUNCH(ctx, K_BA_SCHUR, ba_schur_points_k, dim3((d.n_points + 255) / 256), dim3(256), 0, d);
-    LAUNCH(ctx, K_BA_SCHUR_TILES, ba_schur_tiles_k, dim3(d.n_tiles), dim3(256), 0, d);
+    {   // the instantiation whose stage holds the widest tile: 9 L + 6 pieces of 16 bytes in R x 64
+        const int Lm = pl->schur_lmax;
+        auto lds = [&](int R) { return sizeof(double) * (size_t)std::max(8 * R * 128, 2 * 64 * 36) + sizeof(int32_t) * (size_t)SCHUR_TP * Lm; };
+        if (Lm <= 6) { LAUNCH(ctx, K_BA_SCHUR_TILES, ba_schur_tiles_k<1>, dim3(d.n_tiles), dim3(256), lds(1), d); }
+        else if (Lm <= 13) { LAUNCH(ctx, K_BA_SCHUR_TILES, ba_schur_tiles_k<2>, dim3(d.n_tiles), dim3(256), lds(2), d); }
+        else if (Lm <= 27) { LAUNCH(ctx, K_BA_SCHUR_TILES, ba_schur_tiles_k<4>, dim3(d.n_tiles), dim3(256), lds(4), d); }
+        else {
+            static_assert(9 * SCHUR_LMAX + 6 <= 64 * 10, "widest tile fits the largest instantiation");
+            static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&ba_schur_tiles_k<10>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                               (int)(sizeof(double) * 8 * 10 * 128 + sizeof(int32_t) * SCHUR_TP * SCHUR_LMAX));
+            HIP_TRY(ctx, attr);
+            LAUNCH(ctx, K_BA_SCHUR_TILES, ba_schur_tiles_k<10>, dim3(d.n_tiles), dim3(256), lds(10), d);
+        }
+    }
     const long long items = (long long)d.n_gpairs * 36 * FIN_SPLIT;
     LAUNCH(ctx, K_BA_SCHUR_FINAL, ba_schur_final_k, dim3((unsigned)std::min<long long>(4096, (items + 255) / 256 + 1)), dim3(256), 0, d);
     HIP_TRY(ctx, hipGetLastError());
