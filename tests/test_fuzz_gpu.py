@@ -149,3 +149,24 @@ def test_fuzz_ba_build_and_schur(ctx, oracle, case):
     for k in ("err", "chi2", "rho1", "Hpp", "Hll", "Hpl_val", "b"):
         assert np.abs(g[k] - o[k]).max() <= 1e-9 * max(1e-300, np.abs(o[k]).max()), k
     assert abs(g["robust_chi2"] - o["robust_chi2"]) <= 1e-9 * abs(o["robust_chi2"])
+    # Schur complement of the same system (tiles with padding steps, missing blocks, 1 .. 12 local poses), alone and as one window
+    # of a block-diagonal batch (tiles end at the seam)
+    lam = float(10.0 ** rng.uniform(-4, 3))
+    os_ = oracle.ba_schur(pr, lam)
+    if os_["rc"] != 0:
+        return
+    scale, bscale = np.abs(os_["S"]).max(), max(1e-300, np.abs(os_["bs"]).max())
+    plan = api.BaPlan(ctx, pr)
+    plan.build_dev(); plan.schur_dev(lam)
+    S, bs = plan.download_schur()
+    plan.close()
+    assert np.abs(S - os_["S"]).max() <= 1e-9 * scale and np.abs(bs - os_["bs"]).max() <= 1e-9 * bscale
+    other = synth.ba_problem(int(rng.integers(2, 9)), int(rng.integers(5, 300)), 900 + case + SEED)
+    cat = synth.ba_concat([pr, other])   # (the batch takes the first problem's Huber delta)
+    plan = api.BaPlan(ctx, cat)
+    plan.build_dev(); plan.schur_dev(lam)
+    Sc, bsc = plan.download_schur()
+    plan.close()
+    n6 = S.shape[0]
+    assert np.abs(Sc[:n6, :n6] - os_["S"]).max() <= 1e-9 * scale and np.abs(bsc[:n6] - os_["bs"]).max() <= 1e-9 * bscale
+    assert not Sc[:n6, n6:].any()
