@@ -19,16 +19,16 @@
 //   resize_k        level l-1 -> l, 11-bit fixed-point bilinear (serial dependency between levels)
 //   pyramid2_k      levels l and l+1 from level l-1 in one launch (level l stays in LDS for the second resize); used for
 //                   the pairs (2,3), (4,5), (6,7): 4 pyramid launches instead of 7, levels 2/4/6 are never read back
-//   fast_nms_k      all levels x frames: 64x32 pixel tiles staged in LDS with a 4-px halo;
+//   fast_nms_k      all levels x frames: 128x64 score tiles (124x62 outputs), pixels staged in LDS by LDS-DMA with a halo;
 //                   3-phase (high-speed reject -> dense survivor list -> exact score) so that
 //                   lanes stay busy; 3x3 NMS on an LDS score tile; wave-aggregated append
 //   select_k        one workgroup per (frame, level): histogram threshold (retainBest by
 //                   FAST score), Harris response, radix-select of the n-th best response,
 //                   rank-sort of the survivors by (y, x)
-//   describe_k      one wavefront per keypoint: 43x43 patch in LDS, intensity-centroid
-//                   angle (lane-per-row + wave reduce), separable 7x7 Gaussian of the patch
-//                   (the blurred pyramid is never materialised), 256 rotated tests, 4 ballots
-//                   = 32 descriptor bytes
+//   describe_k      one wavefront per keypoint: 43x43 patch in LDS by LDS-DMA, intensity-centroid
+//                   angle (v_dot4 over the disc's rows + wave reduce), 7x7 Gaussian as a row pass over the
+//                   patch and a column pass evaluated at the 512 sample points only (the blurred pyramid
+//                   is never materialised), 256 rotated tests, 4 ballots = 32 descriptor bytes
 // All integer/float arithmetic is the plain-IEEE evaluation documented in DESIGN.md (built
 // with -ffp-contract=off); cvRound = round-half-even (__float2int_rn / rint).
 #include "common.h"
