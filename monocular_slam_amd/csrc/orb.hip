@@ -147,6 +147,7 @@ __global__ void bgr2gray_k(const uint8_t* __restrict__ src, int w, int h, int st
 // S = src[sx0] a0 + src[sx1] a1 are formed ONCE per source row of the tile's footprint (about 1.2 + 1/8 rows per output
 // row at the pyramid's scale instead of 2) and kept as S >> 4 (u16) in LDS; the vertical pass then reads two of them.
 constexpr int RS_TW = 256, RS_TH = 8, RS_LDS_DW = 1536, RS_HROWS = 16; // 6 + 8 KiB of LDS: 8 workgroups per CU
+constexpr int RS_CPR = RS_LDS_DW / 4 / RS_HROWS;                        // 24 chunks of 16 bytes: the fixed LDS row pitch of the fast path
 __global__ __launch_bounds__(256)
 void resize_k(const uint8_t* __restrict__ src, int spitch, long long sfstride,
               uint8_t* __restrict__ dst, int dw, int dh, int dpitch, long long dfstride,
@@ -172,6 +173,67 @@ void resize_k(const uint8_t* __restrict__ src, int spitch, long long sfstride,
     const int tx = tid & 63, ty = tid >> 6;
     const int x4 = x0 + tx * 4;
     uint8_t* db = dst + b * dfstride;
+    if (dma && cpr <= RS_CPR && nrows <= RS_HROWS) {
+        // The pyramid's own case (scale 1.2: 20-21 chunks per source row): a fixed LDS row pitch of RS_CPR chunks.  Row offsets are
+        // then immediates of the LDS instructions in the unrolled row loops below (no pointer arithmetic per row), and the two
+        // row-table entries of this thread are fetched before the staging instead of after the second barrier.
+        int4 yt2[2];
+#pragma unroll
+        for (int r = 0; r < 2; r++) yt2[r] = ytab[min(y0 + ty * 2 + r, dh - 1)];
+        {
+            const uint8_t* s0 = sb + (size_t)sy_lo * spitch + sxa;
+            const int nch = nrows * RS_CPR;
+#pragma unroll
+            for (int c0 = 0; c0 < RS_HROWS * RS_CPR; c0 += 256) {
+                const int cb = c0 + (tid & ~63), c = cb + (tid & 63);
+                const int r = c / RS_CPR, k = c - r * RS_CPR;
+                if (c < nch && k < cpr) glds16(s0 + __umul24((unsigned)r, (unsigned)spitch) + 16 * k, reinterpret_cast<uint8_t*>(s_src) + cb * 16);
+            }
+        }
+        int o0[4], a0[4], a1[4];
+        {
+            const int4* t4 = reinterpret_cast<const int4*>(xtab + min(x4, (dw + 3) & ~3));
+            const int4 ta = t4[0], tb = t4[1];
+            const int tx_[4] = { ta.x, ta.z, tb.x, tb.z }, ty_[4] = { ta.y, ta.w, tb.y, tb.w };
+#pragma unroll
+            for (int i = 0; i < 4; i++) { o0[i] = (tx_[i] & 0xFFFF) - sxa + ty * (RS_CPR * 16); a0[i] = ty_[i] & 0xFFFF; a1[i] = (int)((unsigned)ty_[i] >> 16); }
+        }
+        __syncthreads();
+        const uint8_t* lds = reinterpret_cast<const uint8_t*>(s_src);
+        uint32_t* hrow = s_h + (ty * RS_TW + tx * 4) / 2;
+#pragma unroll
+        for (int k = 0; k < RS_HROWS / 4; k++) {
+            if (ty + 4 * k < nrows) {   // wave-uniform
+                const uint8_t* row = lds + 4 * k * (RS_CPR * 16);
+                uint32_t h[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) h[i] = (uint32_t)(__umul24(row[o0[i]], a0[i]) + __umul24(row[o0[i] + 1], a1[i])) >> 4; // <= 32640
+                *reinterpret_cast<uint2*>(hrow + 4 * k * (RS_TW / 2)) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+            }
+        }
+        __syncthreads();
+        if (x4 >= dw) return;
+        const uint8_t* hb8 = reinterpret_cast<const uint8_t*>(s_h) + 8 * tx;
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+            const int y = y0 + ty * 2 + r;
+            if (y >= dh) break;
+            const int4 yt = yt2[r]; // {sy0, sy1, b0, b1}
+            const uint16_t* ha = reinterpret_cast<const uint16_t*>(hb8 + (yt.x - sy_lo) * (RS_TW * 2));
+            const uint16_t* hb = reinterpret_cast<const uint16_t*>(hb8 + (yt.y - sy_lo) * (RS_TW * 2));
+            uint32_t out = 0;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const uint32_t A = __umul24((uint32_t)yt.z, ha[i]), Bv = __umul24((uint32_t)yt.w, hb[i]);
+                typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+                const uint32_t hh = __builtin_amdgcn_perm(Bv, A, 0x07060302u);
+                const uint32_t v = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, hh), (us2){1, 1}, 2u, false) >> 2;
+                out |= v << (8 * i);
+            }
+            *reinterpret_cast<uint32_t*>(db + (__umul24((unsigned)y, (unsigned)dpitch) + (unsigned)x4)) = out;
+        }
+        return;
+    }
     if (use_lds) {
         if (dma) {   // nrows * cpr chunks: one global_load_lds_dwordx4 moves 64 of them, no VGPR round trip
             const int nch = nrows * cpr, inv = (65536 + cpr - 1) / cpr;   // c / cpr == (c * inv) >> 16 for c < 640, cpr < 40
@@ -296,6 +358,7 @@ void pyramid2_k(Pyr2Args a)
     __shared__ uint32_t s_src[P2_SH * P2_SDW + 8];        // source footprint (bytes)
     __shared__ uint16_t s_h[P2_SH * P2_AW];               // horizontal sums >> 4: first for A (source rows), then for B (A rows)
     __shared__ uint32_t s_A[P2_AH * P2_AW / 4 + 8];       // A region (bytes), pitch P2_AW
+    __shared__ int4 s_yt[P2_AH + P2_BH];                  // row-table entries of the tile's A rows, then of its B rows
     const int tid = threadIdx.x, b = blockIdx.z;
     const int xB0 = blockIdx.x * P2_BW, yB0 = blockIdx.y * P2_BH;
     const int xB1 = min(xB0 + P2_BW, a.wB) - 1, yB1 = min(yB0 + P2_BH, a.hB) - 1;
@@ -329,7 +392,18 @@ void pyramid2_k(Pyr2Args a)
             if (c < ndw) s_src[r * P2_SDW + c] = sb32[__umul24((unsigned)(sy_lo + r), (unsigned)spitch_dw) + (unsigned)min(sxa / 4 + c, max_dw)];
         }
     }
+    // the row-table entries of the tile's A rows and B rows, as LDS byte offsets into s_h: {first row, second row, b0, b1} -- read
+    // in the vertical passes from LDS instead of from global memory inside the row loops (an exposed load per row)
+    if (tid < cah) {
+        const int4 yt = a.ytA[oy0 + tid];
+        s_yt[tid] = make_int4((yt.x - sy_lo) * (P2_AW * 2), (yt.y - sy_lo) * (P2_AW * 2), yt.z, yt.w);
+    } else if (tid >= 64 && tid < 64 + P2_BH && yB0 + tid - 64 <= yB1) {
+        const int4 yt = a.ytB[yB0 + tid - 64];
+        s_yt[P2_AH + tid - 64] = make_int4((yt.x - oy0) * (P2_AW * 2), (yt.y - oy0) * (P2_AW * 2), yt.z, yt.w);
+    }
     __syncthreads();
+    // The row loops below are written with compile-time trip counts and a guard per step: row offsets become immediates of the LDS
+    // instructions instead of pointer increments (5 of the 21 vector instructions of a horizontal step were pointer arithmetic).
     // ---- A, horizontal: thread = (column group of 4, row lane); 44 groups x 5 row lanes
     {
         const int g = tid % 44, rl = tid / 44;
@@ -340,15 +414,19 @@ void pyramid2_k(Pyr2Args a)
                 const int4 ta = t4[0], tb = t4[1];
                 const int tx_[4] = { ta.x, ta.z, tb.x, tb.z }, ty_[4] = { ta.y, ta.w, tb.y, tb.w };
 #pragma unroll
-                for (int i = 0; i < 4; i++) { o0[i] = (tx_[i] & 0xFFFF) - sxa; a0[i] = ty_[i] & 0xFFFF; a1[i] = (int)((unsigned)ty_[i] >> 16); }
+                for (int i = 0; i < 4; i++) { o0[i] = (tx_[i] & 0xFFFF) - sxa + rl * (P2_SDW * 4); a0[i] = ty_[i] & 0xFFFF; a1[i] = (int)((unsigned)ty_[i] >> 16); }
             }
             const uint8_t* lds = reinterpret_cast<const uint8_t*>(s_src);
-            for (int r = rl; r < nrows; r += 5) {
-                const uint8_t* row = lds + r * (P2_SDW * 4);
-                uint32_t h[4];
+            uint16_t* hrow = s_h + rl * P2_AW + 4 * g;
 #pragma unroll
-                for (int i = 0; i < 4; i++) h[i] = (uint32_t)(__umul24(row[o0[i]], a0[i]) + __umul24(row[o0[i] + 1], a1[i])) >> 4;
-                *reinterpret_cast<uint2*>(&s_h[r * P2_AW + 4 * g]) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+            for (int k = 0; k < (P2_SH + 4) / 5; k++) {
+                if (rl + 5 * k < nrows) {
+                    const uint8_t* row = lds + 5 * k * (P2_SDW * 4);
+                    uint32_t h[4];
+#pragma unroll
+                    for (int i = 0; i < 4; i++) h[i] = (uint32_t)(__umul24(row[o0[i]], a0[i]) + __umul24(row[o0[i] + 1], a1[i])) >> 4;
+                    *reinterpret_cast<uint2*>(hrow + 5 * k * P2_AW) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+                }
             }
         }
     }
@@ -357,24 +435,28 @@ void pyramid2_k(Pyr2Args a)
     {
         const int g = tid % 44, rl = tid / 44;
         if (rl < 5 && 4 * g < caw) {
-            uint8_t* ab = a.A + b * a.afstride;
-            for (int r = rl; r < cah; r += 5) {
-                const int y = oy0 + r;
-                const int4 yt = a.ytA[y];
-                const uint16_t* ha = s_h + (yt.x - sy_lo) * P2_AW + 4 * g;
-                const uint16_t* hb = s_h + (yt.y - sy_lo) * P2_AW + 4 * g;
-                uint32_t out = 0;
+            uint8_t* ab = a.A + b * a.afstride + (__umul24((unsigned)(oy0 + rl), (unsigned)a.apitch) + (unsigned)(ox0 + 4 * g));
+            const uint8_t* hb8 = reinterpret_cast<const uint8_t*>(s_h) + 8 * g;
+            const bool own_x = ox0 + 4 * g < ox1;
 #pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    const uint32_t Av = __umul24((uint32_t)yt.z, ha[i]), Bv = __umul24((uint32_t)yt.w, hb[i]);
-                    typedef unsigned short us2 __attribute__((ext_vector_type(2)));
-                    const uint32_t hh = __builtin_amdgcn_perm(Bv, Av, 0x07060302u);
-                    const uint32_t v = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, hh), (us2){1, 1}, 2u, false) >> 2;
-                    out |= v << (8 * i);
+            for (int k = 0; k < (P2_AH + 4) / 5; k++) {
+                const int r = rl + 5 * k;
+                if (r < cah) {
+                    const int4 yt = s_yt[r];
+                    const uint16_t* ha = reinterpret_cast<const uint16_t*>(hb8 + yt.x);
+                    const uint16_t* hb = reinterpret_cast<const uint16_t*>(hb8 + yt.y);
+                    uint32_t out = 0;
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const uint32_t Av = __umul24((uint32_t)yt.z, ha[i]), Bv = __umul24((uint32_t)yt.w, hb[i]);
+                        typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+                        const uint32_t hh = __builtin_amdgcn_perm(Bv, Av, 0x07060302u);
+                        const uint32_t v = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, hh), (us2){1, 1}, 2u, false) >> 2;
+                        out |= v << (8 * i);
+                    }
+                    s_A[r * (P2_AW / 4) + g] = out;
+                    if (own_x && oy0 + r < oy1) *reinterpret_cast<uint32_t*>(ab + __umul24((unsigned)(5 * k), (unsigned)a.apitch)) = out;
                 }
-                s_A[r * (P2_AW / 4) + g] = out;
-                const int x = ox0 + 4 * g;
-                if (x < ox1 && y < oy1) *reinterpret_cast<uint32_t*>(ab + (__umul24((unsigned)y, (unsigned)a.apitch) + (unsigned)x)) = out;
             }
         }
     }
@@ -389,15 +471,19 @@ void pyramid2_k(Pyr2Args a)
                 const int4 ta = t4[0], tb = t4[1];
                 const int tx_[4] = { ta.x, ta.z, tb.x, tb.z }, ty_[4] = { ta.y, ta.w, tb.y, tb.w };
 #pragma unroll
-                for (int i = 0; i < 4; i++) { o0[i] = (tx_[i] & 0xFFFF) - ox0; a0[i] = ty_[i] & 0xFFFF; a1[i] = (int)((unsigned)ty_[i] >> 16); }
+                for (int i = 0; i < 4; i++) { o0[i] = (tx_[i] & 0xFFFF) - ox0 + rl * P2_AW; a0[i] = ty_[i] & 0xFFFF; a1[i] = (int)((unsigned)ty_[i] >> 16); }
             }
             const uint8_t* lds = reinterpret_cast<const uint8_t*>(s_A);
-            for (int r = rl; r < cah; r += 8) {
-                const uint8_t* row = lds + r * P2_AW;
-                uint32_t h[4];
+            uint16_t* hrow = s_h + rl * P2_AW + 4 * g;
 #pragma unroll
-                for (int i = 0; i < 4; i++) h[i] = (uint32_t)(__umul24(row[o0[i]], a0[i]) + __umul24(row[o0[i] + 1], a1[i])) >> 4;
-                *reinterpret_cast<uint2*>(&s_h[r * P2_AW + 4 * g]) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+            for (int k = 0; k < (P2_AH + 7) / 8; k++) {
+                if (rl + 8 * k < cah) {
+                    const uint8_t* row = lds + 8 * k * P2_AW;
+                    uint32_t h[4];
+#pragma unroll
+                    for (int i = 0; i < 4; i++) h[i] = (uint32_t)(__umul24(row[o0[i]], a0[i]) + __umul24(row[o0[i] + 1], a1[i])) >> 4;
+                    *reinterpret_cast<uint2*>(hrow + 8 * k * P2_AW) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+                }
             }
         }
     }
@@ -405,25 +491,29 @@ void pyramid2_k(Pyr2Args a)
     // ---- B, vertical: 16 rows x 32 groups, two rows per thread
     {
         const int g = tid & 31, rl = tid >> 5;
-        uint8_t* bb = a.Bm + b * a.bfstride;
-        if (xB0 + 4 * g <= xB1)
-            for (int r = rl; r < P2_BH; r += 8) {
-                const int y = yB0 + r;
-                if (y > yB1) break;
-                const int4 yt = a.ytB[y];
-                const uint16_t* ha = s_h + (yt.x - oy0) * P2_AW + 4 * g;
-                const uint16_t* hb = s_h + (yt.y - oy0) * P2_AW + 4 * g;
-                uint32_t out = 0;
+        uint8_t* bb = a.Bm + b * a.bfstride + (__umul24((unsigned)(yB0 + rl), (unsigned)a.bpitch) + (unsigned)(xB0 + 4 * g));
+        const uint8_t* hb8 = reinterpret_cast<const uint8_t*>(s_h) + 8 * g;
+        if (xB0 + 4 * g <= xB1) {
 #pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    const uint32_t Av = __umul24((uint32_t)yt.z, ha[i]), Bv = __umul24((uint32_t)yt.w, hb[i]);
-                    typedef unsigned short us2 __attribute__((ext_vector_type(2)));
-                    const uint32_t hh = __builtin_amdgcn_perm(Bv, Av, 0x07060302u);
-                    const uint32_t v = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, hh), (us2){1, 1}, 2u, false) >> 2;
-                    out |= v << (8 * i);
+            for (int k = 0; k < P2_BH / 8; k++) {
+                const int r = rl + 8 * k;
+                if (yB0 + r <= yB1) {
+                    const int4 yt = s_yt[P2_AH + r];
+                    const uint16_t* ha = reinterpret_cast<const uint16_t*>(hb8 + yt.x);
+                    const uint16_t* hb = reinterpret_cast<const uint16_t*>(hb8 + yt.y);
+                    uint32_t out = 0;
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const uint32_t Av = __umul24((uint32_t)yt.z, ha[i]), Bv = __umul24((uint32_t)yt.w, hb[i]);
+                        typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+                        const uint32_t hh = __builtin_amdgcn_perm(Bv, Av, 0x07060302u);
+                        const uint32_t v = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, hh), (us2){1, 1}, 2u, false) >> 2;
+                        out |= v << (8 * i);
+                    }
+                    *reinterpret_cast<uint32_t*>(bb + __umul24((unsigned)(8 * k), (unsigned)a.bpitch)) = out;
                 }
-                *reinterpret_cast<uint32_t*>(bb + (__umul24((unsigned)y, (unsigned)a.bpitch) + (unsigned)(xB0 + 4 * g))) = out;
             }
+        }
     }
 }
 
