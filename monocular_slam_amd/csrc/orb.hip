@@ -729,11 +729,19 @@ __device__ __forceinline__ float harris_response(const uint8_t* __restrict__ img
     // HarrisResponses(img, pts, 7, 0.04f): 7x7 block of Sobel-like gradients from a 9x9 window
     int a = 0, bb = 0, c = 0;
     int win[9][9];
+    // nine bytes per row from three aligned dwords (level rows are dword aligned and a keypoint is >= 31 px from the border):
+    // 27 loads per lane instead of 81 byte loads, which are bound by the issue rate of the vector memory pipeline
     const uint8_t* p = img + (size_t)(y - 4) * pitch + (x - 4);
+    const unsigned o = (unsigned)(uintptr_t)p & 3u;
+    const uint32_t* p4 = reinterpret_cast<const uint32_t*>(p - o);
+    const int pitch4 = pitch >> 2;
 #pragma unroll
-    for (int r = 0; r < 9; r++)
+    for (int r = 0; r < 9; r++) {
+        const uint32_t d0 = p4[r * pitch4], d1 = p4[r * pitch4 + 1], d2 = p4[r * pitch4 + 2];
+        const uint32_t w[3] = { __builtin_amdgcn_alignbyte(d1, d0, o), __builtin_amdgcn_alignbyte(d2, d1, o), __builtin_amdgcn_alignbyte(0u, d2, o) };
 #pragma unroll
-        for (int j = 0; j < 9; j++) win[r][j] = p[(size_t)r * pitch + j];
+        for (int j = 0; j < 9; j++) win[r][j] = (int)((w[j >> 2] >> (8 * (j & 3))) & 255u);
+    }
 #pragma unroll
     for (int r = 1; r <= 7; r++)
 #pragma unroll
@@ -752,6 +760,22 @@ __device__ __forceinline__ uint32_t float_key(float f)
 {
     uint32_t u = __float_as_uint(f);
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u); // order-preserving
+}
+
+// Suffix sums of the 256-bin histogram by the first wavefront (lane l owns bins 4 l .. 4 l + 3): inc[q] = number of entries in
+// bins >= 4 l + q.  Replaces a scan by one thread, whose 256 dependent LDS reads were the longest step of select_k.
+__device__ __forceinline__ void hist_suffix(const uint32_t* s_hist, int lane, uint32_t (&h)[4], uint32_t (&inc)[4])
+{
+    const uint4 hv = *reinterpret_cast<const uint4*>(s_hist + 4 * lane);
+    h[0] = hv.x; h[1] = hv.y; h[2] = hv.z; h[3] = hv.w;
+    uint32_t sfx = h[0] + h[1] + h[2] + h[3];
+    const uint32_t own = sfx;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t t = __shfl_down(sfx, off);
+        if (lane + off < 64) sfx += t;
+    }
+    inc[3] = sfx - own + h[3]; inc[2] = inc[3] + h[2]; inc[1] = inc[2] + h[1]; inc[0] = inc[1] + h[0];
 }
 
 __global__ __launch_bounds__(SEL_THREADS)
@@ -776,16 +800,18 @@ void select_k(OrbDev od)
 
     // FAST score histogram of this (frame, level) from its candidate list
     if (tid < 256) s_hist[tid] = 0;
-    if (tid == 0) { s_nA = 0; s_nS = 0; }
+    if (tid == 0) { s_nA = 0; s_nS = 0; s_T = 256; }
     __syncthreads();
     for (int i = tid; i < ncand; i += SEL_THREADS) atomicAdd(&s_hist[cand[i] >> 24], 1u);
     __syncthreads();
-    if (tid == 0) {
-        // retainBest(n1) as a set: keep score s iff #(score > s) < n1; n1 == 0 clears
-        int T = 256, gt = 0;
-        if (n1 > 0)
-            for (int s = 255; s >= 0; s--) { if (gt >= n1) break; T = s; gt += (int)s_hist[s]; }
-        s_T = T;
+    if (tid < 64) {
+        // retainBest(n1) as a set: keep score s iff #(score > s) < n1, i.e. T = the lowest such s; n1 == 0 clears (T = 256)
+        uint32_t h[4], inc[4];
+        hist_suffix(s_hist, tid, h, inc);
+        int Tl = 256;
+#pragma unroll
+        for (int q = 3; q >= 0; q--) if ((int)(inc[q] - h[q]) < n1) Tl = 4 * tid + q;   // (true for a range of bins that ends at 255)
+        atomicMin(&s_T, Tl);
     }
     __syncthreads();
     const int T = s_T;
@@ -821,10 +847,22 @@ void select_k(OrbDev od)
                 if ((k & mask) == prefix) atomicAdd(&s_hist[(k >> shift) & 255], 1u);
             }
             __syncthreads();
-            if (tid == 0) {
-                int k = s_k, bin = 255;
-                for (; bin > 0; bin--) { if ((int)s_hist[bin] >= k) break; k -= (int)s_hist[bin]; }
-                s_k = k; s_prefix = prefix | ((uint32_t)bin << shift); s_mask = mask | (255u << shift);
+            if (tid < 64) {
+                // the bin that holds the k-th largest key: the highest bin >= 1 whose inclusive suffix count reaches k, else bin 0;
+                // k then drops by the entries in the bins above it
+                uint32_t h[4], inc[4];
+                hist_suffix(s_hist, tid, h, inc);
+                const int k = s_k;
+                int bl = 0;
+#pragma unroll
+                for (int q = 0; q < 4; q++) if ((int)inc[q] >= k && 4 * tid + q >= 1) bl = 4 * tid + q;
+                int bin = bl;
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) bin = max(bin, __shfl_xor(bin, off));
+                if (tid == (bin >> 2)) {
+                    s_k = k - (int)(inc[bin & 3] - h[bin & 3]);
+                    s_prefix = prefix | ((uint32_t)bin << shift); s_mask = mask | (255u << shift);
+                }
             }
             __syncthreads();
         }
