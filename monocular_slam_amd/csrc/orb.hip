@@ -778,12 +778,31 @@ __device__ __forceinline__ void hist_suffix(const uint32_t* s_hist, int lane, ui
     inc[3] = sfx - own + h[3]; inc[2] = inc[3] + h[2]; inc[1] = inc[2] + h[1]; inc[0] = inc[1] + h[0];
 }
 
+// One digit of the radix select, by the first wavefront: the bin that holds the k-th largest key is the highest bin >= 1 whose
+// inclusive suffix count reaches k, else bin 0; k then drops by the entries in the bins above it.
+__device__ __forceinline__ void radix_step(const uint32_t* s_hist, int lane, int shift, uint32_t prefix, uint32_t mask, int* s_k, uint32_t* s_prefix, uint32_t* s_mask)
+{
+    uint32_t h[4], inc[4];
+    hist_suffix(s_hist, lane, h, inc);
+    const int k = *s_k;
+    int bl = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) if ((int)inc[q] >= k && 4 * lane + q >= 1) bl = 4 * lane + q;
+    int bin = bl;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) bin = max(bin, __shfl_xor(bin, off));
+    if (lane == (bin >> 2)) {
+        *s_k = k - (int)(inc[bin & 3] - h[bin & 3]);
+        *s_prefix = prefix | ((uint32_t)bin << shift); *s_mask = mask | (255u << shift);
+    }
+}
+
 __global__ __launch_bounds__(SEL_THREADS)
 void select_k(OrbDev od)
 {
     extern __shared__ uint8_t dyn[];  // survivors: uint2[max_kpts]
     __shared__ uint32_t s_hist[256];
-    __shared__ int s_T, s_nA, s_nS;
+    __shared__ int s_T, s_nA, s_nS, s_nKeep;
     __shared__ uint32_t s_prefix, s_mask;
     __shared__ int s_k;
     const int l = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
@@ -811,75 +830,118 @@ void select_k(OrbDev od)
         int Tl = 256;
 #pragma unroll
         for (int q = 3; q >= 0; q--) if ((int)(inc[q] - h[q]) < n1) Tl = 4 * tid + q;   // (true for a range of bins that ends at 255)
-        atomicMin(&s_T, Tl);
+        int Tw = Tl;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) Tw = min(Tw, __shfl_xor(Tw, off));
+        if (tid == 0) { s_T = Tw; if (Tw >= 256) s_nKeep = 0; }
+        if (Tw < 256 && tid == (Tw >> 2)) s_nKeep = (int)inc[Tw & 3];   // candidates with score >= T
     }
     __syncthreads();
     const int T = s_T;
-    // compact the kept candidates (unordered; order is restored by the final rank sort)
-    for (int i0 = 0; i0 < ncand; i0 += SEL_THREADS) {
-        int i = i0 + tid;
-        uint32_t c = i < ncand ? cand[i] : 0;
-        bool keep = i < ncand && (int)(c >> 24) >= T;
-        unsigned long long bal = __ballot(keep);
-        int base = 0;
-        if ((tid & 63) == 0 && bal) base = atomicAdd(&s_nA, __popcll(bal));
-        base = __shfl(base, 0);
-        if (keep) candA[base + __popcll(bal & ((1ull << (tid & 63)) - 1ull))] = c;
-    }
-    __syncthreads();
-    const int nA = s_nA;
-    for (int i = tid; i < nA; i += SEL_THREADS) {
-        uint32_t c = candA[i];
-        respA[i] = harris ? harris_response(img, lv.pitch, (int)(c & 0xFFF), (int)((c >> 12) & 0xFFF)) : (float)(c >> 24);
-    }
-    __syncthreads();
-    // second retainBest(nf) by response: radix-select the nf-th largest key, keep key >= it
-    uint32_t Tkey = 0; // keep everything
-    if (harris && nf > 0 && nA > nf) {
-        if (tid == 0) { s_prefix = 0; s_mask = 0; s_k = nf; }
+    const bool clear_all = (nf == 0) || (harris && n1 == 0);
+    if (s_nKeep <= od.max_kpts) {
+        // ---- the kept candidates fit the survivor storage in LDS (the normal case: 2 nf + ties): candidate and response live there
+        // as pairs from here on; no global round trip between the steps
+        for (int i0 = 0; i0 < ncand; i0 += SEL_THREADS) {
+            int i = i0 + tid;
+            uint32_t c = i < ncand ? cand[i] : 0;
+            bool keep = i < ncand && (int)(c >> 24) >= T;
+            unsigned long long bal = __ballot(keep);
+            int base = 0;
+            if ((tid & 63) == 0 && bal) base = atomicAdd(&s_nA, __popcll(bal));
+            base = __shfl(base, 0);
+            if (keep) surv[base + __popcll(bal & ((1ull << (tid & 63)) - 1ull))].x = c;
+        }
         __syncthreads();
-        for (int shift = 24; shift >= 0; shift -= 8) {
-            if (tid < 256) s_hist[tid] = 0;
+        const int nA = s_nA;
+        for (int i = tid; i < nA; i += SEL_THREADS) {
+            const uint32_t c = surv[i].x;
+            surv[i].y = __float_as_uint(harris ? harris_response(img, lv.pitch, (int)(c & 0xFFF), (int)((c >> 12) & 0xFFF)) : (float)(c >> 24));
+        }
+        __syncthreads();
+        uint32_t Tkey = 0; // keep everything
+        if (harris && nf > 0 && nA > nf) {
+            if (tid == 0) { s_prefix = 0; s_mask = 0; s_k = nf; }
             __syncthreads();
-            const uint32_t prefix = s_prefix, mask = s_mask;
-            for (int i = tid; i < nA; i += SEL_THREADS) {
-                uint32_t k = float_key(respA[i]);
-                if ((k & mask) == prefix) atomicAdd(&s_hist[(k >> shift) & 255], 1u);
-            }
-            __syncthreads();
-            if (tid < 64) {
-                // the bin that holds the k-th largest key: the highest bin >= 1 whose inclusive suffix count reaches k, else bin 0;
-                // k then drops by the entries in the bins above it
-                uint32_t h[4], inc[4];
-                hist_suffix(s_hist, tid, h, inc);
-                const int k = s_k;
-                int bl = 0;
-#pragma unroll
-                for (int q = 0; q < 4; q++) if ((int)inc[q] >= k && 4 * tid + q >= 1) bl = 4 * tid + q;
-                int bin = bl;
-#pragma unroll
-                for (int off = 32; off > 0; off >>= 1) bin = max(bin, __shfl_xor(bin, off));
-                if (tid == (bin >> 2)) {
-                    s_k = k - (int)(inc[bin & 3] - h[bin & 3]);
-                    s_prefix = prefix | ((uint32_t)bin << shift); s_mask = mask | (255u << shift);
+            for (int shift = 24; shift >= 0; shift -= 8) {
+                if (tid < 256) s_hist[tid] = 0;
+                __syncthreads();
+                const uint32_t prefix = s_prefix, mask = s_mask;
+                for (int i = tid; i < nA; i += SEL_THREADS) {
+                    uint32_t k = float_key(__uint_as_float(surv[i].y));
+                    if ((k & mask) == prefix) atomicAdd(&s_hist[(k >> shift) & 255], 1u);
                 }
+                __syncthreads();
+                if (tid < 64) radix_step(s_hist, tid, shift, prefix, mask, &s_k, &s_prefix, &s_mask);
+                __syncthreads();
             }
+            Tkey = s_prefix;
+        }
+        // survivors, compacted in place: entry i moves to pos <= i, and every entry of a chunk is read before any is written
+        for (int i0 = 0; i0 < nA; i0 += SEL_THREADS) {
+            int i = i0 + tid;
+            const uint2 e = i < nA ? surv[i] : make_uint2(0u, 0u);
+            bool keep = i < nA && !clear_all && float_key(__uint_as_float(e.y)) >= Tkey;
+            unsigned long long bal = __ballot(keep);
+            int base = 0;
+            if ((tid & 63) == 0 && bal) base = atomicAdd(&s_nS, __popcll(bal));
+            base = __shfl(base, 0);
+            int pos = base + __popcll(bal & ((1ull << (tid & 63)) - 1ull));
+            __syncthreads();
+            if (keep) surv[pos] = make_uint2(e.x & 0xFFFFFFu, e.y);
             __syncthreads();
         }
-        Tkey = s_prefix;
-    }
-    const bool clear_all = (nf == 0) || (harris && n1 == 0);
-    // survivors -> LDS
-    for (int i0 = 0; i0 < nA; i0 += SEL_THREADS) {
-        int i = i0 + tid;
-        float r = i < nA ? respA[i] : 0.f;
-        bool keep = i < nA && !clear_all && float_key(r) >= Tkey;
-        unsigned long long bal = __ballot(keep);
-        int base = 0;
-        if ((tid & 63) == 0 && bal) base = atomicAdd(&s_nS, __popcll(bal));
-        base = __shfl(base, 0);
-        int pos = base + __popcll(bal & ((1ull << (tid & 63)) - 1ull));
-        if (keep && pos < od.max_kpts) surv[pos] = make_uint2(candA[i] & 0xFFFFFFu, __float_as_uint(r));
+    } else {
+        // ---- more kept candidates than the LDS storage holds (a long run of equal FAST scores): through the global lists
+        // compact the kept candidates (unordered; order is restored by the final rank sort)
+        for (int i0 = 0; i0 < ncand; i0 += SEL_THREADS) {
+            int i = i0 + tid;
+            uint32_t c = i < ncand ? cand[i] : 0;
+            bool keep = i < ncand && (int)(c >> 24) >= T;
+            unsigned long long bal = __ballot(keep);
+            int base = 0;
+            if ((tid & 63) == 0 && bal) base = atomicAdd(&s_nA, __popcll(bal));
+            base = __shfl(base, 0);
+            if (keep) candA[base + __popcll(bal & ((1ull << (tid & 63)) - 1ull))] = c;
+        }
+        __syncthreads();
+        const int nA = s_nA;
+        for (int i = tid; i < nA; i += SEL_THREADS) {
+            uint32_t c = candA[i];
+            respA[i] = harris ? harris_response(img, lv.pitch, (int)(c & 0xFFF), (int)((c >> 12) & 0xFFF)) : (float)(c >> 24);
+        }
+        __syncthreads();
+        // second retainBest(nf) by response: radix-select the nf-th largest key, keep key >= it
+        uint32_t Tkey = 0; // keep everything
+        if (harris && nf > 0 && nA > nf) {
+            if (tid == 0) { s_prefix = 0; s_mask = 0; s_k = nf; }
+            __syncthreads();
+            for (int shift = 24; shift >= 0; shift -= 8) {
+                if (tid < 256) s_hist[tid] = 0;
+                __syncthreads();
+                const uint32_t prefix = s_prefix, mask = s_mask;
+                for (int i = tid; i < nA; i += SEL_THREADS) {
+                    uint32_t k = float_key(respA[i]);
+                    if ((k & mask) == prefix) atomicAdd(&s_hist[(k >> shift) & 255], 1u);
+                }
+                __syncthreads();
+                if (tid < 64) radix_step(s_hist, tid, shift, prefix, mask, &s_k, &s_prefix, &s_mask);
+                __syncthreads();
+            }
+            Tkey = s_prefix;
+        }
+        // survivors -> LDS
+        for (int i0 = 0; i0 < nA; i0 += SEL_THREADS) {
+            int i = i0 + tid;
+            float r = i < nA ? respA[i] : 0.f;
+            bool keep = i < nA && !clear_all && float_key(r) >= Tkey;
+            unsigned long long bal = __ballot(keep);
+            int base = 0;
+            if ((tid & 63) == 0 && bal) base = atomicAdd(&s_nS, __popcll(bal));
+            base = __shfl(base, 0);
+            int pos = base + __popcll(bal & ((1ull << (tid & 63)) - 1ull));
+            if (keep && pos < od.max_kpts) surv[pos] = make_uint2(candA[i] & 0xFFFFFFu, __float_as_uint(r));
+        }
     }
     __syncthreads();
     const int nS = s_nS;

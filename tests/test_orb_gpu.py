@@ -99,6 +99,28 @@ def test_response_ties_are_all_kept_then_overflow_is_an_error(ctx, oracle):
         oracle.orb_extract(board, _oracle_params(oracle, p), cap=64)
 
 
+def test_more_score_ties_than_the_lds_lists_hold(oracle):
+    """936 level-0 corners tie on FAST score (so the first retainBest keeps them all) but differ in Harris response (pixels at
+    the corners of the 9x9 Harris window, outside the FAST ring, differ by a few grey levels): with a context of 300 keypoints
+    select_k cannot keep the kept candidates in LDS and goes through its global lists; the result is the oracle's."""
+    yy, xx = np.mgrid[0:480, 0:640]
+    board = np.where(((yy % 16) == 8) & ((xx % 16) == 8), 220, 20).astype(np.uint8)
+    rng = np.random.default_rng(12)
+    for cy in range(8, 480, 16):
+        for cx in range(8, 640, 16):
+            for dy, dx in ((-4, -4), (-4, 4), (4, -4), (4, 4)):
+                board[cy + dy, cx + dx] = 20 + int(rng.integers(0, 8))
+    small = api.Context(device=0, max_w=640, max_h=480, max_kpts=300, batch=1)
+    try:
+        p = api.default_orb_params(50)
+        kg, dg = small.orb_extract(board, p)
+        ko, do = oracle.orb_extract(board, _oracle_params(oracle, p), cap=8192)
+        assert 0 < (ko["octave"] == 0).sum() < 100 and len(ko) <= 300
+        _same_keypoints(kg, dg, ko, do)
+    finally:
+        small.close()
+
+
 def test_batched_device_extract(ctx, oracle):
     B, w, h, cap = 4, 640, 480, 1024
     frames = np.stack([synth.textured_frame(w, h, 100 + i) for i in range(B)])
