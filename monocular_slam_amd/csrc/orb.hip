@@ -723,6 +723,7 @@ void fast_nms_k(OrbDev od)
 // ---------------------------------------------------------------- K3: select
 constexpr int SEL_THREADS = 1024;
 constexpr int SEL_LEVEL_CAP = 4096; // survivors of one level are rank-sorted in LDS (32 KiB)
+constexpr int SEL_RC = 16;           // candidates per thread that select_k keeps in registers between its two passes over the list
 
 __device__ __forceinline__ float harris_response(const uint8_t* __restrict__ img, int pitch, int x, int y)
 {
@@ -821,7 +822,14 @@ void select_k(OrbDev od)
     if (tid < 256) s_hist[tid] = 0;
     if (tid == 0) { s_nA = 0; s_nS = 0; s_T = 256; }
     __syncthreads();
-    for (int i = tid; i < ncand; i += SEL_THREADS) atomicAdd(&s_hist[cand[i] >> 24], 1u);
+    // (the first SEL_RC x 1024 candidates are read ONCE, all loads of a thread in flight together, and kept in registers for the
+    // compaction below: a loop of load -> LDS atomic exposes the memory latency once per iteration)
+    uint32_t creg[SEL_RC];
+#pragma unroll
+    for (int j = 0; j < SEL_RC; j++) { const int i = tid + j * SEL_THREADS; creg[j] = i < ncand ? cand[i] : 0u; }
+#pragma unroll
+    for (int j = 0; j < SEL_RC; j++) if (tid + j * SEL_THREADS < ncand) atomicAdd(&s_hist[creg[j] >> 24], 1u);
+    for (int i = tid + SEL_RC * SEL_THREADS; i < ncand; i += SEL_THREADS) atomicAdd(&s_hist[cand[i] >> 24], 1u);
     __syncthreads();
     if (tid < 64) {
         // retainBest(n1) as a set: keep score s iff #(score > s) < n1, i.e. T = the lowest such s; n1 == 0 clears (T = 256)
@@ -842,16 +850,17 @@ void select_k(OrbDev od)
     if (s_nKeep <= od.max_kpts) {
         // ---- the kept candidates fit the survivor storage in LDS (the normal case: 2 nf + ties): candidate and response live there
         // as pairs from here on; no global round trip between the steps
-        for (int i0 = 0; i0 < ncand; i0 += SEL_THREADS) {
-            int i = i0 + tid;
-            uint32_t c = i < ncand ? cand[i] : 0;
+        auto keep_one = [&](int i, uint32_t c) {
             bool keep = i < ncand && (int)(c >> 24) >= T;
             unsigned long long bal = __ballot(keep);
             int base = 0;
             if ((tid & 63) == 0 && bal) base = atomicAdd(&s_nA, __popcll(bal));
             base = __shfl(base, 0);
             if (keep) surv[base + __popcll(bal & ((1ull << (tid & 63)) - 1ull))].x = c;
-        }
+        };
+#pragma unroll
+        for (int j = 0; j < SEL_RC; j++) if (j * SEL_THREADS < ncand) keep_one(tid + j * SEL_THREADS, creg[j]);
+        for (int i0 = SEL_RC * SEL_THREADS; i0 < ncand; i0 += SEL_THREADS) { const int i = i0 + tid; keep_one(i, i < ncand ? cand[i] : 0u); }
         __syncthreads();
         const int nA = s_nA;
         for (int i = tid; i < nA; i += SEL_THREADS) {
@@ -1047,12 +1056,17 @@ void describe_k(OrbDev od, DescArgs out)
     const int g = bx * DESC_WAVES + wave; // keypoint index inside the frame
     // level offsets (<= 16 counts)
     int total = 0, l = -1, off = 0;
-    for (int i = 0; i < od.L; i++) {
-        int c = od.sel_cnt[b * od.L + i];
-        if (l < 0 && g < total + c) { l = i; off = total; }
-        total += c;
-    }
     const int st = od.frame_status[b];
+    {   // (all counts fetched before the first is used: one memory latency, not one per level)
+        int cnt[MSLAM_MAX_LEVELS];
+#pragma unroll
+        for (int i = 0; i < MSLAM_MAX_LEVELS; i++) cnt[i] = i < od.L ? od.sel_cnt[b * od.L + i] : 0;
+#pragma unroll
+        for (int i = 0; i < MSLAM_MAX_LEVELS; i++) {
+            if (l < 0 && i < od.L && g < total + cnt[i]) { l = i; off = total; }
+            total += cnt[i];
+        }
+    }
     const bool bad = st != MSLAM_OK || total > out.cap;
     if (g == 0 && lane == 0) {
         out.n_out[b] = bad ? 0 : total;
