@@ -392,6 +392,11 @@ void pyramid2_k(Pyr2Args a)
             if (c < ndw) s_src[r * P2_SDW + c] = sb32[__umul24((unsigned)(sy_lo + r), (unsigned)spitch_dw) + (unsigned)min(sxa / 4 + c, max_dw)];
         }
     }
+    // the column-table entries of this thread's A and B column groups: fetched here, before the barrier, so that their latency
+    // passes under the staging (they were loaded after the barriers, in front of the loops that need them)
+    int4 tA0 = make_int4(0, 0, 0, 0), tA1 = tA0, tB0 = tA0, tB1 = tA0;
+    if (tid / 44 < 5 && 4 * (tid % 44) < caw) { const int4* t4 = reinterpret_cast<const int4*>(a.xtA + ox0 + 4 * (tid % 44)); tA0 = t4[0]; tA1 = t4[1]; }
+    if (xB0 + 4 * (tid & 31) <= xB1) { const int4* t4 = reinterpret_cast<const int4*>(a.xtB + xB0 + 4 * (tid & 31)); tB0 = t4[0]; tB1 = t4[1]; }
     // the row-table entries of the tile's A rows and B rows, as LDS byte offsets into s_h: {first row, second row, b0, b1} -- read
     // in the vertical passes from LDS instead of from global memory inside the row loops (an exposed load per row)
     if (tid < cah) {
@@ -410,8 +415,7 @@ void pyramid2_k(Pyr2Args a)
         if (rl < 5 && 4 * g < caw) {
             int o0[4], a0[4], a1[4];
             {
-                const int4* t4 = reinterpret_cast<const int4*>(a.xtA + ox0 + 4 * g);   // padded table: no clamps
-                const int4 ta = t4[0], tb = t4[1];
+                const int4 ta = tA0, tb = tA1;   // (padded table: no clamps)
                 const int tx_[4] = { ta.x, ta.z, tb.x, tb.z }, ty_[4] = { ta.y, ta.w, tb.y, tb.w };
 #pragma unroll
                 for (int i = 0; i < 4; i++) { o0[i] = (tx_[i] & 0xFFFF) - sxa + rl * (P2_SDW * 4); a0[i] = ty_[i] & 0xFFFF; a1[i] = (int)((unsigned)ty_[i] >> 16); }
@@ -467,8 +471,7 @@ void pyramid2_k(Pyr2Args a)
         if (xB0 + 4 * g <= xB1) {
             int o0[4], a0[4], a1[4];
             {
-                const int4* t4 = reinterpret_cast<const int4*>(a.xtB + xB0 + 4 * g);   // padded table: no clamps
-                const int4 ta = t4[0], tb = t4[1];
+                const int4 ta = tB0, tb = tB1;   // (padded table: no clamps)
                 const int tx_[4] = { ta.x, ta.z, tb.x, tb.z }, ty_[4] = { ta.y, ta.w, tb.y, tb.w };
 #pragma unroll
                 for (int i = 0; i < 4; i++) { o0[i] = (tx_[i] & 0xFFFF) - ox0 + rl * P2_AW; a0[i] = ty_[i] & 0xFFFF; a1[i] = (int)((unsigned)ty_[i] >> 16); }
