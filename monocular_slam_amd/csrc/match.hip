@@ -250,10 +250,17 @@ void knn2_finalize(const uint2* __restrict__ part, const int32_t* __restrict__ n
         bool keep = false;
         uint32_t best = KEY_NONE, second = KEY_NONE;
         if (qi < nq && nt >= 2) {
-            for (int c = 0; c < used; c++) {
-                uint2 p = part[((size_t)b * nchunks + c) * cap + qi];
-                top2_update(best, second, p.x);
-                if (p.y != KEY_NONE) top2_update(best, second, p.y);
+            for (int c0 = 0; c0 < used; c0 += 4) {   // four partial results in flight together (one memory latency, not four)
+                uint2 p[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) p[u] = c0 + u < used ? part[((size_t)b * nchunks + c0 + u) * cap + qi] : make_uint2(KEY_NONE, KEY_NONE);
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    if (c0 + u < used) {
+                        top2_update(best, second, p[u].x);
+                        if (p[u].y != KEY_NONE) top2_update(best, second, p[u].y);
+                    }
+                }
             }
         }
         if (qi < nq) {

@@ -516,9 +516,18 @@ void ransac_select_k(const int32_t* __restrict__ counts, const int32_t* __restri
     const bool adaptive = confidence > 0. && confidence < 1.;
     int niters = H, best = -1, maxgood = 0;
     if (state) { niters = state[3 * b]; best = state[3 * b + 1]; maxgood = state[3 * b + 2]; }
-    for (int i0 = h_lo; i0 < niters && i0 < h_hi; i0 += 64) {
+    // (eight chunks of 64 counts are fetched together: one memory latency per 512 counts instead of one per 64)
+    constexpr int SEL_PF = 8;
+    for (int g0 = h_lo; g0 < niters && g0 < h_hi; g0 += 64 * SEL_PF) {
+      int vv[SEL_PF];
+#pragma unroll
+      for (int u = 0; u < SEL_PF; u++) { const int i = g0 + 64 * u + lane; vv[u] = i < h_hi ? c[i] : -1; }
+#pragma unroll
+      for (int u = 0; u < SEL_PF; u++) {
+        const int i0 = g0 + 64 * u;
+        if (!(i0 < niters && i0 < h_hi)) break;
         const int i = i0 + lane;
-        const int v = i < h_hi ? c[i] : -1;
+        const int v = vv[u];
         int floor_ = maxgood > sample_size - 1 ? maxgood : sample_size - 1;
         unsigned long long bal = __ballot(i < niters && v > floor_);
         while (bal) { // record breakers in index order
@@ -534,6 +543,7 @@ void ransac_select_k(const int32_t* __restrict__ counts, const int32_t* __restri
                     niters = ransac_update_iters(confidence, (double)(n_points - good) / n_points, sample_size, niters);
             }
         }
+      }
     }
     if (lane == 0) {
         best_out[b] = best;
