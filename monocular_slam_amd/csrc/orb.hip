@@ -805,7 +805,7 @@ __global__ __launch_bounds__(SEL_THREADS)
 void select_k(OrbDev od)
 {
     extern __shared__ uint8_t dyn[];  // survivors: uint2[max_kpts]
-    __shared__ uint32_t s_hist[256];
+    __shared__ __attribute__((aligned(16))) uint32_t s_hist[256];   // (read as uint4 by hist_suffix)
     __shared__ int s_T, s_nA, s_nS, s_nKeep;
     __shared__ uint32_t s_prefix, s_mask;
     __shared__ int s_k;
