@@ -381,7 +381,7 @@ void ba_schur_tiles_k(BaDev d)
     constexpr int MAIN = 8 * SLOT > 2 * 64 * 36 ? 8 * SLOT : 2 * 64 * 36;   // 4 wavefronts x {stage, B Dinv}; later the cross-wavefront sum
     constexpr int LCAP = (64 * R - 6) / 9;              // local poses this instantiation can stage
     constexpr int CR = (6 * LCAP + 63) / 64;            // block rows per lane
-    extern __shared__ double s_dyn[];
+    extern __shared__ __attribute__((aligned(16))) double s_dyn[];   // (16-byte pieces)
     int32_t* const s_tb = reinterpret_cast<int32_t*>(s_dyn + MAIN);   // [SCHUR_TP][L] block index table of the tile
     const int tile = blockIdx.x, tid = threadIdx.x, w = tid >> 6, ln = tid & 63;
     const int L = d.tile_pose_ptr[tile + 1] - d.tile_pose_ptr[tile];
