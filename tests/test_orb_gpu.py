@@ -121,6 +121,18 @@ def test_more_score_ties_than_the_lds_lists_hold(oracle):
         small.close()
 
 
+def test_noise_frame_with_far_more_candidates_than_select_keeps_in_registers(ctx, oracle):
+    """A 1080p frame of independent random pixels: several hundred thousand FAST maxima on level 0, far beyond the 16384
+    candidates select_k reads into registers, so its remainder loops over the global list run; result = the oracle's."""
+    rng = np.random.default_rng(77)
+    img = rng.integers(0, 256, (1080, 1920), dtype=np.uint8)
+    p = api.default_orb_params(2000)
+    kg, dg = ctx.orb_extract(img, p)
+    ko, do = oracle.orb_extract(img, _oracle_params(oracle, p), cap=8192)
+    assert len(ko) >= 2000
+    _same_keypoints(kg, dg, ko, do)
+
+
 def test_batched_device_extract(ctx, oracle):
     B, w, h, cap = 4, 640, 480, 1024
     frames = np.stack([synth.textured_frame(w, h, 100 + i) for i in range(B)])
