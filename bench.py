@@ -25,6 +25,8 @@ import time
 
 import numpy as np
 
+METRIC = "frames/sec (extract+match+PnP) at 1920x1080, 2k kpts/frame"
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -219,8 +221,12 @@ def main():
             th.start()
             th.join(float(os.environ.get("BENCH_COMM_TIMEOUT", "120")))
             if th.is_alive():
-                box["err"] = "RCCL communicator creation did not return within the watchdog time"
-                collective["watchdog_fired"] = True
+                # the creation thread may still finish later and would then share tbs[0].pnp_ctx's stream with the timed loop,
+                # and the peers may still be inside ncclCommInitRank: nothing measured after this point could be trusted.
+                # Report and leave (no in-process restart); the launcher ends the other ranks.
+                print(json.dumps({"metric": METRIC, "value": None, "unit": "frames/s", "n_gpus": world, "rank": rank,
+                                  "error": "RCCL communicator creation did not return within the watchdog time (BENCH_COMM_TIMEOUT)"}), flush=True)
+                os._exit(3)
         else:
             box["err"] = uid_err or "no RCCL unique id"
         all_ok = "comm" in box
@@ -401,7 +407,7 @@ def main():
         frames_total = world * B * T * args.steps
         value = frames_total / elapsed
         out = {
-            "metric": "frames/sec (extract+match+PnP) at 1920x1080, 2k kpts/frame", "value": value, "unit": "frames/s",
+            "metric": METRIC, "value": value, "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/i32 (extract, match) + f64 (PnP)",
             "data": "synthetic",
@@ -433,9 +439,6 @@ def main():
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
-    if collective is not None and collective.get("watchdog_fired"):
-        sys.stdout.flush()
-        os._exit(0)   # a thread is stuck inside RCCL: do not wait for it in the interpreter's teardown
 
 
 def roofline_blocks(kern, kern_x, nprof, SB, NS, value, world) -> dict:

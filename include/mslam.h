@@ -400,7 +400,8 @@ int mslam_argmax_counts(const int32_t* counts, int n, int* best, int* best_count
 typedef struct mslam_comm mslam_comm;
 /* Binds RCCL now (optional; the first communicator does it otherwise): the librccl.so.1 beside the libamdhip64 this library
  * is linked to, by absolute path -- a process that also holds another ROCm stack under the same SONAMEs (a PyTorch wheel)
- * should call this BEFORE loading that stack.  path_out (optional) receives the file that was bound. */
+ * should call this BEFORE loading that stack.  path_out (optional) receives the file that was bound.
+ * The environment variable MSLAM_RCCL_PATH replaces the search by one explicit file. */
 int mslam_comm_preload(char* path_out, int cap);
 int mslam_comm_unique_id(uint8_t id[MSLAM_COMM_ID_BYTES]);
 int mslam_comm_create(mslam_ctx* ctx, const uint8_t id[MSLAM_COMM_ID_BYTES], int rank, int nranks, mslam_comm** out);
@@ -411,8 +412,12 @@ int mslam_comm_allgather_i32_dev(mslam_comm* comm, const int32_t* send_dev, int 
 int mslam_comm_allgather_i32(mslam_comm* comm, const int32_t* send_host, int n, int32_t* recv_host);
 int mslam_comm_destroy(mslam_comm* comm);
 /* One process driving ngpu contexts on distinct devices: rank g contributes send + g*n (host);
- * recv (host, ngpu*n) receives the gathered vector.  Communicators are created on first use per device list. */
+ * recv (host, ngpu*n) receives the gathered vector.  Communicators are created on first use per device list and cached
+ * for the life of the process (calls are serialised by a library lock; on an error every stream of the call is drained
+ * before it returns).  mslam_comm_shutdown destroys the cached communicators: call it with the contexts' streams idle,
+ * before the contexts are destroyed; optional. */
 int mslam_allgather_i32(mslam_ctx* const* ctxs, int ngpu, const int32_t* send, int n, int32_t* recv);
+int mslam_comm_shutdown(void);
 
 #ifdef __cplusplus
 }

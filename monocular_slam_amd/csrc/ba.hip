@@ -1051,9 +1051,9 @@ static int schur_launch(mslam_ba_plan* pl)
         else if (Lm <= 27) { LAUNCH(ctx, K_BA_SCHUR_TILES, ba_schur_tiles_k<4>, dim3(d.n_tiles), dim3(256), lds(4), d); }
         else {
             static_assert(9 * SCHUR_LMAX + 6 <= 64 * 10, "widest tile fits the largest instantiation");
-            static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&ba_schur_tiles_k<10>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                               (int)(sizeof(double) * 8 * 10 * 128 + sizeof(int32_t) * SCHUR_TP * SCHUR_LMAX));
-            HIP_TRY(ctx, attr);
+            // per launch, on the context's device (a cached result would be the first device's, failures included)
+            HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&ba_schur_tiles_k<10>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             (int)(sizeof(double) * 8 * 10 * 128 + sizeof(int32_t) * SCHUR_TP * SCHUR_LMAX)));
             LAUNCH(ctx, K_BA_SCHUR_TILES, ba_schur_tiles_k<10>, dim3(d.n_tiles), dim3(256), lds(10), d);
         }
     }

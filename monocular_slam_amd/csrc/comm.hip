@@ -16,6 +16,7 @@
 #include "common.h"
 #include <rccl/rccl.h>
 #include <dlfcn.h>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -48,18 +49,30 @@ bool rccl_load()
     // is bound to, by absolute path.  A process may hold a second ROCm stack (a PyTorch wheel bundles its own libamdhip64 and
     // librccl under the same SONAMEs); binding by name would pick whichever was loaded first, and an RCCL running on the other
     // HIP runtime cannot use this runtime's streams or device pointers.  RTLD_NOW | RTLD_DEEPBIND: its own symbols first, bound now.
+    // MSLAM_RCCL_PATH replaces the candidate list by one explicit path (deployments with RCCL elsewhere; the loader's failure test).
     std::vector<std::string> names;
-    Dl_info info;
-    if (dladdr(reinterpret_cast<void*>(&hipGetDeviceCount), &info) && info.dli_fname) {
-        std::string dir(info.dli_fname);
-        const size_t slash = dir.rfind('/');
-        if (slash != std::string::npos) names.push_back(dir.substr(0, slash) + "/librccl.so.1");
+    const char* forced = std::getenv("MSLAM_RCCL_PATH");
+    if (forced && *forced) {
+        names.push_back(forced);
+    } else {
+        Dl_info info;
+        if (dladdr(reinterpret_cast<void*>(&hipGetDeviceCount), &info) && info.dli_fname) {
+            std::string dir(info.dli_fname);
+            const size_t slash = dir.rfind('/');
+            if (slash != std::string::npos) names.push_back(dir.substr(0, slash) + "/librccl.so.1");
+        }
+        names.push_back("/opt/rocm/lib/librccl.so.1");
+        names.push_back("librccl.so.1");
     }
-    names.push_back("/opt/rocm/lib/librccl.so.1");
-    names.push_back("librccl.so.1");
     void* h = nullptr;
-    for (const std::string& n : names) { h = dlopen(n.c_str(), RTLD_NOW | RTLD_LOCAL | RTLD_DEEPBIND); if (h) { g_rccl.path = n; break; } }
-    if (!h) { g_rccl.err = std::string("dlopen librccl: ") + (dlerror() ? dlerror() : "not found"); return false; }
+    std::string why;
+    for (const std::string& n : names) {
+        h = dlopen(n.c_str(), RTLD_NOW | RTLD_LOCAL | RTLD_DEEPBIND);
+        if (h) { g_rccl.path = n; break; }
+        const char* e = dlerror();   // one call: dlerror() clears the state it returns
+        why += std::string(why.empty() ? "" : "; ") + (e ? e : (n + ": not found"));
+    }
+    if (!h) { g_rccl.err = "dlopen librccl: " + why; return false; }
 #define SYM(field, name) \
     *reinterpret_cast<void**>(&g_rccl.field) = dlsym(h, name); \
     if (!g_rccl.field) { g_rccl.err = std::string("dlsym ") + name; dlclose(h); return false; }
@@ -91,8 +104,11 @@ struct mslam_comm {
     } while (0)
 
 // single-process multi-GPU communicators, keyed by the device list
+// (process-lifetime: the communicators are destroyed by mslam_comm_shutdown or left to process exit; g_all_mu serialises
+// the whole single-process call, so two host threads cannot race on the cache or interleave their group calls)
 struct AllComm { std::vector<int> devs; std::vector<ncclComm_t> comms; };
 static std::vector<AllComm> g_all;
+static std::mutex g_all_mu;
 
 extern "C" {
 
@@ -192,6 +208,7 @@ int mslam_allgather_i32(mslam_ctx* const* ctxs, int ngpu, const int32_t* send, i
     std::vector<int> devs(ngpu);
     for (int g = 0; g < ngpu; g++) devs[g] = ctxs[g]->device;
     for (int a = 0; a < ngpu; a++) for (int b = a + 1; b < ngpu; b++) if (devs[a] == devs[b]) return MSLAM_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(g_all_mu);
     AllComm* ac = nullptr;
     for (auto& e : g_all) if (e.devs == devs) ac = &e;
     if (!ac) {
@@ -200,6 +217,8 @@ int mslam_allgather_i32(mslam_ctx* const* ctxs, int ngpu, const int32_t* send, i
         g_all.push_back(e);
         ac = &g_all.back();
     }
+    // after a failure every stream that may already hold work of this call is drained before the caller sees the error
+    auto drain = [&](int upto) { for (int g = 0; g < upto; g++) { (void)hipSetDevice(devs[g]); (void)hipStreamSynchronize(ctxs[g]->stream); } };
     std::vector<int32_t*> bufs(ngpu, nullptr);
     int status = MSLAM_OK;
     for (int g = 0; g < ngpu && status == MSLAM_OK; g++) {
@@ -209,19 +228,35 @@ int mslam_allgather_i32(mslam_ctx* const* ctxs, int ngpu, const int32_t* send, i
         if (status == MSLAM_OK && hipMemcpyAsync(bufs[g], send + (size_t)g * n, (size_t)n * 4, hipMemcpyHostToDevice, ctxs[g]->stream) != hipSuccess)
             status = MSLAM_ERR_HIP;
     }
-    if (status != MSLAM_OK) return status;
-    RCCL_TRY(c0, g_rccl.GroupStart());
+    if (status != MSLAM_OK) { drain(ngpu); return status; }
+    ncclResult_t r = g_rccl.GroupStart();
+    if (r != ncclSuccess) { drain(ngpu); c0->last_hip_error = std::string("ncclGroupStart: ") + g_rccl.GetErrorString(r); return MSLAM_ERR_HIP; }
+    for (int g = 0; g < ngpu && r == ncclSuccess; g++) {
+        (void)hipSetDevice(devs[g]);
+        r = g_rccl.AllGather(bufs[g], bufs[g] + n, (size_t)n, ncclInt32, ac->comms[g], ctxs[g]->stream);
+    }
+    const ncclResult_t re = g_rccl.GroupEnd();   // always closes the group, also after a failed enqueue
+    if (r == ncclSuccess) r = re;
+    if (r != ncclSuccess) { drain(ngpu); c0->last_hip_error = std::string("ncclAllGather: ") + g_rccl.GetErrorString(r); return MSLAM_ERR_HIP; }
+    (void)hipSetDevice(devs[0]);
+    hipError_t he = hipMemcpyAsync(recv, bufs[0] + n, (size_t)n * 4 * ngpu, hipMemcpyDeviceToHost, ctxs[0]->stream);
     for (int g = 0; g < ngpu; g++) {
         (void)hipSetDevice(devs[g]);
-        ncclResult_t r = g_rccl.AllGather(bufs[g], bufs[g] + n, (size_t)n, ncclInt32, ac->comms[g], ctxs[g]->stream);
-        if (r != ncclSuccess) { (void)g_rccl.GroupEnd(); c0->last_hip_error = std::string("ncclAllGather: ") + g_rccl.GetErrorString(r); return MSLAM_ERR_HIP; }
+        const hipError_t hs = hipStreamSynchronize(ctxs[g]->stream);
+        if (he == hipSuccess) he = hs;
     }
-    RCCL_TRY(c0, g_rccl.GroupEnd());
-    for (int g = 0; g < ngpu; g++) {
-        (void)hipSetDevice(devs[g]);
-        if (g == 0) HIP_TRY(c0, hipMemcpyAsync(recv, bufs[0] + n, (size_t)n * 4 * ngpu, hipMemcpyDeviceToHost, ctxs[0]->stream));
-        HIP_TRY(ctxs[g], hipStreamSynchronize(ctxs[g]->stream));
-    }
+    if (he != hipSuccess) { c0->last_hip_error = std::string("mslam_allgather_i32: ") + hipGetErrorString(he); return MSLAM_ERR_HIP; }
+    return MSLAM_OK;
+}
+
+// Destroys the cached single-process communicators (call after the contexts' streams are idle and before the contexts are
+// destroyed; optional: without it they live until process exit).
+int mslam_comm_shutdown(void)
+{
+    std::lock_guard<std::mutex> lk(g_all_mu);
+    for (auto& e : g_all)
+        for (size_t g = 0; g < e.comms.size(); g++) { (void)hipSetDevice(e.devs[g]); if (e.comms[g]) (void)g_rccl.CommDestroy(e.comms[g]); }
+    g_all.clear();
     return MSLAM_OK;
 }
 

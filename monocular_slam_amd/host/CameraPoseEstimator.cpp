@@ -49,7 +49,10 @@ void CameraPoseEstimator::matchFeatures(const cv::Mat& d1, const cv::Mat& d2, st
     int n = 0;
     DeviceFeatures* a = rt.deviceFeatures(d1.device);
     DeviceFeatures* b = rt.deviceFeatures(d2.device);
-    if (a && b && a->cap == b->cap && a->n == nq && b->n == nt) {
+    // a twin counts only while the host rows it was attached to are unchanged (cv::Mat semantics allow in-place edits)
+    if (a && (a->n != nq || d1.cols != 32 || a->content != contentHash(d1.data, (size_t)nq * 32))) a = nullptr;
+    if (b && (b->n != nt || d2.cols != 32 || b->content != contentHash(d2.data, (size_t)nt * 32))) b = nullptr;
+    if (a && b && a->cap == b->cap) {
         // both descriptor sets are still on the device (left there by FeatureExtractor::extract): kNN-2, ratio test and the
         // ordered compaction run there, only the surviving (query, train, distance) triples come back
         const size_t cap = (size_t)a->cap;

@@ -30,6 +30,7 @@ void FeatureExtractor::extract(const cv::Mat& img, std::vector<cv::KeyPoint>& ke
         MslamRuntime::check(mslam_memcpy_d2h_async(ctx, kps.data(), dk, sizeof(mslam_keypoint) * (size_t)n), "mslam_memcpy_d2h_async");
         MslamRuntime::check(mslam_memcpy_d2h(ctx, descriptors.data, twin->desc, (size_t)n * 32), "mslam_memcpy_d2h");
     }
+    twin->content = contentHash(descriptors.data, (size_t)n * 32);
     descriptors.device = twin;
     keypoints.resize((size_t)n);
     for (int i = 0; i < n; i++) {

@@ -54,7 +54,8 @@ public:
     size_t step = 0;
     // Optional device-resident twin of the contents (cv::UMat's role): an opaque owning handle that shallow copies share
     // and clone() drops.  FeatureExtractor attaches the frame's descriptors on the GPU here so that matchFeatures can
-    // match without uploading them again (Runtime.h: DeviceFeatures).  Whoever writes through `data` must reset it.
+    // match without uploading them again (Runtime.h: DeviceFeatures).  The twin records a content hash of the host rows;
+    // consumers verify it before trusting the device copy, so in-place edits through at<>/ptr<>/data are safe.
     std::shared_ptr<void> device;
 private:
     int type_ = 0;

@@ -5,6 +5,7 @@
 // matches two such twins with mslam_match_knn2_batch_dev without any upload (the reference keeps everything in host
 // cv::Mats, src/Frame.h:22-34 -- there is no device there to keep anything on).
 #pragma once
+#include <cstdint>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -17,7 +18,27 @@ struct DeviceFeatures {
     uint8_t* desc = nullptr;   // cap x 32, 256-byte aligned
     int32_t* n_dev = nullptr;  // 1 int32: number of rows
     int n = 0, cap = 0;
+    uint64_t content = 0;      // contentHash of the host rows the twin was attached to (cv::Mat hands out mutable access:
+                               // a caller may edit descriptors in place; the twin is used only while the host rows still hash to this)
 };
+
+// 64-bit content hash of n bytes (n a multiple of 8 for descriptor rows; a tail is folded bytewise): four independent
+// multiply-rotate lanes, a few microseconds for a 2000 x 32 descriptor matrix
+inline uint64_t contentHash(const uint8_t* p, size_t n)
+{
+    uint64_t h[4] = { 0x9E3779B97F4A7C15ull, 0xC2B2AE3D27D4EB4Full, 0x165667B19E3779F9ull, 0x27D4EB2F165667C5ull };
+    size_t i = 0;
+    for (; i + 32 <= n; i += 32)
+        for (int k = 0; k < 4; k++) {
+            uint64_t w; __builtin_memcpy(&w, p + i + 8 * k, 8);
+            h[k] = (h[k] ^ w) * 0xFF51AFD7ED558CCDull;
+            h[k] = (h[k] << 29) | (h[k] >> 35);
+        }
+    uint64_t r = n;
+    for (; i < n; i++) r = (r ^ p[i]) * 0x100000001B3ull;
+    for (int k = 0; k < 4; k++) { r ^= h[k]; r *= 0xC4CEB9FE1A85EC53ull; r ^= r >> 31; }
+    return r;
+}
 
 class MslamRuntime {
 public:

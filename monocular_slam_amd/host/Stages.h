@@ -32,6 +32,8 @@ class CameraPoseEstimator : public ProcessingNode {
 public:
     CameraPoseEstimator();
     void estimate(DataManager& data, int frameIdx);
+    // matchFeatures (:200-213) for callers outside the stage (tools, tests): kNN-2 + ratio test, query = d1, train = d2
+    void match(const cv::Mat& d1, const cv::Mat& d2, std::vector<cv::DMatch>& matches, float ratio = 0.8f) { matchFeatures(d1, d2, matches, ratio); }
     virtual void process(DataManager& data, int frameIdx) override;
     virtual bool validationCheck(DataManager& data, int frameIdx) override;
 

@@ -14,12 +14,13 @@
 int main(int argc, char** argv)
 {
     if (argc < 3) { std::fprintf(stderr, "usage: %s in.bin out.txt [--ba] [--ba-window K] [--nfeatures N] [--no-dist] [--pnp-hyps H] [--pnp-thr T]\n", argv[0]); return 2; }
-    bool ba = false, nodist = false;
+    bool ba = false, nodist = false, twinCheck = false;
     int nfeatures = 500, pnpH = 100, baWindow = 0;
     double pnpThr = 8.0;
     for (int i = 3; i < argc; i++) {
         if (!std::strcmp(argv[i], "--ba")) ba = true;
         else if (!std::strcmp(argv[i], "--no-dist")) nodist = true;
+        else if (!std::strcmp(argv[i], "--twin-check")) twinCheck = true;
         else if (!std::strcmp(argv[i], "--ba-window") && i + 1 < argc) { ba = true; baWindow = std::atoi(argv[++i]); }
         else if (!std::strcmp(argv[i], "--nfeatures") && i + 1 < argc) nfeatures = std::atoi(argv[++i]);
         else if (!std::strcmp(argv[i], "--pnp-hyps") && i + 1 < argc) pnpH = std::atoi(argv[++i]);
@@ -43,6 +44,36 @@ int main(int argc, char** argv)
         dm.frames.push_back(f);
     }
     if (!in) { std::fprintf(stderr, "short read\n"); return 2; }
+    if (twinCheck) {
+        // Descriptors stay on the device as the twin of Features::descriptors.  cv::Mat allows in-place edits, so the twin must
+        // not be trusted after one: match (twin path), edit frame 1's descriptors in place, match again, and compare both
+        // results with the host-pointer form on clones (clone() drops the twin).
+        try {
+            if (n < 2) { std::fprintf(stderr, "--twin-check needs two frames\n"); return 2; }
+            FeatureExtractor fe; fe.params.nfeatures = nfeatures;
+            CameraPoseEstimator cpe;
+            fe.process(dm, 0); fe.process(dm, 1);
+            cv::Mat& d0 = dm.frames[0].features.descriptors;
+            cv::Mat& d1 = dm.frames[1].features.descriptors;
+            auto same = [](const std::vector<cv::DMatch>& a, const std::vector<cv::DMatch>& b) {
+                if (a.size() != b.size()) return false;
+                for (size_t i = 0; i < a.size(); i++) if (a[i].queryIdx != b[i].queryIdx || a[i].trainIdx != b[i].trainIdx || a[i].distance != b[i].distance) return false;
+                return true;
+            };
+            std::vector<cv::DMatch> twin0, host0, twin1, host1;
+            cpe.match(d1, d0, twin0);
+            cpe.match(d1.clone(), d0.clone(), host0);
+            const int rows = d0.rows < 64 ? d0.rows : 64;
+            for (int r = 0; r < rows; r++) for (int c = 0; c < 32; c++) d0.at<uint8_t>(r, c) = (uint8_t)(d0.at<uint8_t>(r, c) ^ 0xFF);   // in-place edit
+            cpe.match(d1, d0, twin1);
+            cpe.match(d1.clone(), d0.clone(), host1);
+            const bool ok = same(twin0, host0) && same(twin1, host1) && !same(twin0, twin1) && !twin0.empty();
+            FILE* out = std::fopen(argv[2], "w");
+            std::fprintf(out, "twin_check %s %zu %zu\n", ok ? "ok" : "FAILED", twin0.size(), twin1.size());
+            std::fclose(out);
+            return ok ? 0 : 1;
+        } catch (const std::exception& e) { std::fprintf(stderr, "twin check failed: %s\n", e.what()); return 1; }
+    }
     try {
         ProcessingPipeline slam;
         FeatureExtractor* fe = new FeatureExtractor();

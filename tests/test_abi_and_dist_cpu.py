@@ -120,3 +120,25 @@ def test_two_rank_gloo_allgather_of_hypothesis_counts(tmp_path):
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, o
         assert f"rank {r} ok" in o
+
+
+def test_rccl_loader_failure_returns_no_device_instead_of_crashing():
+    """The lazy RCCL bind with no loadable library (the case it exists for): every entry that needs RCCL returns
+    MSLAM_ERR_NO_DEVICE; none of them may crash while formatting the loader's message (dlerror() is read once per attempt)."""
+    code = r'''
+import ctypes as C, sys
+sys.path.insert(0, sys.argv[1])
+from monocular_slam_amd import api
+L = api.lib()
+buf = C.create_string_buffer(64)
+idb = (C.c_uint8 * 128)()
+L.mslam_comm_unique_id.argtypes = [C.c_void_p]
+for _ in range(2):   # the second round exercises the already-failed state
+    assert L.mslam_comm_preload(buf, 64) == api.ERR_NO_DEVICE
+    assert L.mslam_comm_unique_id(idb) == api.ERR_NO_DEVICE
+assert L.mslam_comm_shutdown() == api.OK
+print("loader ok")
+'''
+    env = dict(os.environ, MSLAM_RCCL_PATH="/nonexistent/librccl.so.1")
+    r = subprocess.run([sys.executable, "-c", code, ROOT], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=120)
+    assert r.returncode == 0 and "loader ok" in r.stdout, r.stdout

@@ -216,3 +216,19 @@ def test_cpp_bench_binary_runs_the_batched_path():
     assert r.returncode == 0, r.stderr + r.stdout
     d = json.loads(r.stdout.strip().splitlines()[-1])
     assert d["valid_outputs"] is True and d["value"] > 0 and d["mean_keypoints"] > 400 and d["mean_ratio_survivors"] > 60
+
+
+def test_device_twin_is_not_trusted_after_an_in_place_edit(tmp_path, sequence):
+    """Features::descriptors keeps a device twin so that matching does not upload it again; cv::Mat hands out mutable
+    access, so an in-place edit of the host rows must make matchFeatures fall back to them (content hash in the twin)."""
+    frames, _ = sequence
+    n, h, w = frames[:2].shape
+    inp, out = tmp_path / "seq.bin", tmp_path / "out.txt"
+    with open(inp, "wb") as f:
+        f.write(struct.pack("<4i", n, w, h, 1))
+        f.write(np.ascontiguousarray(synth.K_TUM1, np.float64).tobytes())
+        f.write(np.ascontiguousarray(frames[:2]).tobytes())
+    r = subprocess.run([DEMO, str(inp), str(out), "--twin-check"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr + open(out).read() if os.path.exists(out) else r.stderr
+    tok = open(out).read().split()
+    assert tok[:2] == ["twin_check", "ok"] and int(tok[2]) > 50
