@@ -529,36 +529,39 @@ __device__ __forceinline__ int ring_ofs(int k)
     return dy[k] * FP_PITCH + dx[k];
 }
 
-// exact cornerScore<16>: max over the 16 arcs of 9 of min(d) / min(-d), minus 1, with d[k] = centre - ring pixel k
-// (AND-doubling over the ring: minima of 2, 4, 8 consecutive, then the 9th).  Evaluated on packed 16-bit pairs
-// D[k] = (d[k], d[k + 8]), k = 0..7 (|d| <= 255): v_pk_min/max_i16 work on two ring positions
-// per instruction and the "+8" partner of a pair is a half swap, which the VOP3P op_sel modifiers provide for free.
+// exact cornerScore<16>: max over the 16 arcs of 9 of min(d) / min(-d), minus 1, with d[k] = centre - ring pixel k.
+// Evaluated on packed 16-bit pairs D[k] = (d[k], d[k + 8]), k = 0..7 (|d| <= 255): v_pk_min/max_i16 work on two ring
+// positions per instruction and the "+8" partner of a pair is a half swap, which the VOP3P op_sel modifiers provide for free.
+// Two arcs that start at k and k + 1 share the window d[k+1 .. k+8], so only the 8 windows of 8 that start at an odd position
+// are formed (by doubling: 2, 4, 8 consecutive, 4 packed instructions per level), and each is extended by the ring pixel on
+// either side (46 packed instructions for both polarities; doubling over all 16 positions took 78).
 typedef short s2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ s2v swp(s2v a) { return __builtin_shufflevector(a, a, 1, 0); }
 __device__ __forceinline__ int fast_exact_score_pk(const s2v* D)
 {
-    s2v M2[8], N2[8], M4[8], N4[8], M8[8], N8[8];
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-        const s2v nx = k + 1 < 8 ? D[k + 1] : swp(D[0]);
-        M2[k] = __builtin_elementwise_min(D[k], nx); N2[k] = __builtin_elementwise_max(D[k], nx);
-    }
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-        const s2v mx = k + 2 < 8 ? M2[k + 2] : swp(M2[k + 2 - 8]), nx = k + 2 < 8 ? N2[k + 2] : swp(N2[k + 2 - 8]);
-        M4[k] = __builtin_elementwise_min(M2[k], mx); N4[k] = __builtin_elementwise_max(N2[k], nx);
-    }
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-        const s2v mx = k + 4 < 8 ? M4[k + 4] : swp(M4[k - 4]), nx = k + 4 < 8 ? N4[k + 4] : swp(N4[k - 4]);
-        M8[k] = __builtin_elementwise_min(M4[k], mx); N8[k] = __builtin_elementwise_max(N4[k], nx);
-    }
-    s2v A = __builtin_elementwise_min(M8[0], swp(D[0])), Bv = __builtin_elementwise_max(N8[0], swp(D[0]));
-#pragma unroll
-    for (int k = 1; k < 8; k++) {
-        A = __builtin_elementwise_max(A, __builtin_elementwise_min(M8[k], swp(D[k])));
-        Bv = __builtin_elementwise_min(Bv, __builtin_elementwise_max(N8[k], swp(D[k])));
-    }
+#define PMIN(a, b) __builtin_elementwise_min(a, b)
+#define PMAX(a, b) __builtin_elementwise_max(a, b)
+    // windows of 2 and 4 starting at ring positions 1, 3, 5, 7 (low halves) and 9, 11, 13, 15 (high halves)
+    const s2v D8 = swp(D[0]);   // (d[8], d[0]) = position 8 | 16
+    const s2v m2_1 = PMIN(D[1], D[2]), m2_3 = PMIN(D[3], D[4]), m2_5 = PMIN(D[5], D[6]), m2_7 = PMIN(D[7], D8);
+    const s2v n2_1 = PMAX(D[1], D[2]), n2_3 = PMAX(D[3], D[4]), n2_5 = PMAX(D[5], D[6]), n2_7 = PMAX(D[7], D8);
+    const s2v m4_1 = PMIN(m2_1, m2_3), m4_3 = PMIN(m2_3, m2_5), m4_5 = PMIN(m2_5, m2_7), m4_7 = PMIN(m2_7, swp(m2_1));
+    const s2v n4_1 = PMAX(n2_1, n2_3), n4_3 = PMAX(n2_3, n2_5), n4_5 = PMAX(n2_5, n2_7), n4_7 = PMAX(n2_7, swp(n2_1));
+    // windows of 8: j .. j + 7
+    const s2v m8_1 = PMIN(m4_1, m4_5), m8_3 = PMIN(m4_3, m4_7), m8_5 = PMIN(m4_5, swp(m4_1)), m8_7 = PMIN(m4_7, swp(m4_3));
+    const s2v n8_1 = PMAX(n4_1, n4_5), n8_3 = PMAX(n4_3, n4_7), n8_5 = PMAX(n4_5, swp(n4_1)), n8_7 = PMAX(n4_7, swp(n4_3));
+    // arcs of 9: the window extended by position j - 1, or by position j + 8 (the partner half of D[j]);
+    // max(min(w, x), min(w, y)) = min(w, max(x, y)), so each window costs one instruction per polarity and one to pair x, y
+    s2v A = PMIN(m8_1, PMAX(D[0], swp(D[1])));
+    s2v Bv = PMAX(n8_1, PMIN(D[0], swp(D[1])));
+    A = PMAX(A, PMIN(m8_3, PMAX(D[2], swp(D[3]))));
+    Bv = PMIN(Bv, PMAX(n8_3, PMIN(D[2], swp(D[3]))));
+    A = PMAX(A, PMIN(m8_5, PMAX(D[4], swp(D[5]))));
+    Bv = PMIN(Bv, PMAX(n8_5, PMIN(D[4], swp(D[5]))));
+    A = PMAX(A, PMIN(m8_7, PMAX(D[6], swp(D[7]))));
+    Bv = PMIN(Bv, PMAX(n8_7, PMIN(D[6], swp(D[7]))));
+#undef PMIN
+#undef PMAX
     const int amax = max((int)A.x, (int)A.y), bmin = min((int)Bv.x, (int)Bv.y);
     return max(amax, -bmin) - 1;
 }
@@ -571,7 +574,7 @@ void fast_nms_k(OrbDev od)
     __shared__ uint32_t s_pix[FP_H * FP_PITCH / 4];
     __shared__ uint8_t s_score[FS_H * FS_W];
     __shared__ uint16_t s_list[FS_H * FS_W];
-    __shared__ int s_n1, s_ne, s_base;
+    __shared__ int s_n1, s_ne, s_base, s_nc;
     // NMS maxima (<= 63 x 31 per tile) are collected in the pixel tile's storage, which is dead after phase 2
     uint32_t* s_emit = s_pix;
     static_assert(((FT_W + 1) / 2) * ((FT_H + 1) / 2) * 4 <= FP_H * FP_PITCH, "emit buffer must fit in the pixel tile");
@@ -588,7 +591,7 @@ void fast_nms_k(OrbDev od)
     const uint8_t* img = lv.img + b * lv.frame_stride;
     const int tid = threadIdx.x;
 
-    if (tid == 0) { s_n1 = 0; s_ne = 0; }
+    if (tid == 0) { s_n1 = 0; s_ne = 0; s_nc = 0; }
     for (int i = tid; i < FS_H * FS_W / 4; i += FAST_THREADS) reinterpret_cast<uint32_t*>(s_score)[i] = 0;
     // ---- stage the pixel tile by LDS-DMA: LDS byte i of row r = image byte x = (ox - 5 + i) of row (oy - 4 + r).  The tile
     // grid is laid out so that ox - 5 is a multiple of 4 (level rows are dword aligned), hence score column 0 sits on an LDS
@@ -671,33 +674,54 @@ void fast_nms_k(OrbDev od)
     __syncthreads();
     if (od.ablate == 2) return;
     const uint8_t* pix = reinterpret_cast<const uint8_t*>(s_pix);
-    // ---- phase 2: segment test + exact score for the survivors (dense lanes)
+    // ---- phase 2: segment test + exact score for the survivors (dense lanes).  The corners (about 40 % of the survivors)
+    // are appended to a list of their own in the upper half of s_list, so that phase 3 runs on dense lanes as well; a tile with
+    // more survivors than half the list holds (never seen outside synthetic noise) walks the survivor list again instead.
     const int n1 = s_n1;
-    for (int j = tid; j < n1; j += FAST_THREADS) {
-        const int i = s_list[j];
-        const int sy = i / FS_W, sx = i % FS_W;
-        const uint8_t* p = pix + (sy + 3) * FP_PITCH + (sx + 4);
-        const uint32_t v = p[0];
-        // packed differences D[k] = (v - p[k], v - p[k + 8]).  The segment test needs no masks of its own: an arc of 9 ring
-        // pixels all darker than v - thr exists iff max over arcs of min(d) > thr, all brighter iff min over arcs of
-        // max(d) < -thr -- the two quantities the exact score is made of.  So: score + 1 > thr <=> corner.
-        const s2v V2 = __builtin_bit_cast(s2v, v | (v << 16));
-        s2v D[8];
+    constexpr int CL0 = FS_H * FS_W / 2;
+    const bool clist = n1 <= CL0;   // workgroup-uniform
+    for (int j0 = 0; j0 < n1; j0 += FAST_THREADS) {
+        const int j = j0 + tid;
+        int i = 0, sc = -1;
+        if (j < n1) {
+            i = s_list[j];
+            const int sy = i / FS_W, sx = i % FS_W;
+            const uint8_t* p = pix + (sy + 3) * FP_PITCH + (sx + 4);
+            const uint32_t v = p[0];
+            // packed differences D[k] = (v - p[k], v - p[k + 8]).  The segment test needs no masks of its own: an arc of 9 ring
+            // pixels all darker than v - thr exists iff max over arcs of min(d) > thr, all brighter iff min over arcs of
+            // max(d) < -thr -- the two quantities the exact score is made of.  So: score + 1 > thr <=> corner.
+            const s2v V2 = __builtin_bit_cast(s2v, v | (v << 16));
+            s2v D[8];
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const uint32_t pk = (uint32_t)p[ring_ofs(k)] | ((uint32_t)p[ring_ofs(k + 8)] << 16);
-            D[k] = V2 - __builtin_bit_cast(s2v, pk);
+            for (int k = 0; k < 8; k++) {
+                const uint32_t pk = (uint32_t)p[ring_ofs(k)] | ((uint32_t)p[ring_ofs(k + 8)] << 16);
+                D[k] = V2 - __builtin_bit_cast(s2v, pk);
+            }
+            sc = fast_exact_score_pk(D);
         }
-        const int sc = fast_exact_score_pk(D);
-        if (sc >= thr) s_score[i] = (uint8_t)sc;
+        const bool corner = sc >= thr;
+        if (corner) s_score[i] = (uint8_t)sc;
+        if (clist) {
+            const unsigned long long cm = __builtin_amdgcn_ballot_w64(corner);
+            if (cm) { // wave-uniform
+                int base = 0;
+                if (lane == 0) base = atomicAdd(&s_nc, __popcll(cm));
+                base = __shfl(base, 0);
+                const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(cm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cm, 0u));
+                if (corner) s_list[CL0 + base + rank] = (uint16_t)i;
+            }
+        }
     }
     __syncthreads();
     if (od.ablate == 3) return;
     // ---- phase 3: 3x3 non-max suppression on the score tile, outputs inside the ROI only
     const int out_w = min(FT_W, lv.roi_x0 + lv.roi_w - ox), out_h = min(FT_H, lv.roi_y0 + lv.roi_h - oy);
     const int out_x0 = 1 + max(0, lv.roi_x0 - ox);   // the first tile column starts up to 3 px left of the ROI
-    for (int j = tid; j < n1; j += FAST_THREADS) {
-        const int i = s_list[j];
+    const int n3 = clist ? s_nc : n1;
+    const uint16_t* l3 = clist ? s_list + CL0 : s_list;
+    for (int j = tid; j < n3; j += FAST_THREADS) {
+        const int i = l3[j];
         const int sy = i / FS_W, sx = i % FS_W;
         const int sc = s_score[i];
         // branch-free: eight neighbour bytes, their maximum by v_max3, one compare (a chain of && here compiles to a chain of
