@@ -708,6 +708,7 @@ struct PnpArgs {
     int32_t* counts;  // [B][H]
     int32_t* best; int32_t* best_cnt;
     double* Rt; double* rvec; double* tvec; uint8_t* inliers; int32_t* n_inliers; int32_t* status;
+    int f32_tier;     // 1: pnp_score_k decides in single precision first (MSLAM_PNP_F32=0 keeps the double test alone)
 };
 
 __device__ __forceinline__ void project_pt(const double* Rt, double fx, double fy, double cx, double cy, const double* k,
@@ -1096,11 +1097,212 @@ __device__ __forceinline__ void pnp_score_body(const PnpArgs& a, int b, int h0, 
     }
 }
 
+__device__ __forceinline__ bool pnp_has_dist(const double* k)
+{
+    return (k[0] != 0.0) | (k[1] != 0.0) | (k[2] != 0.0) | (k[3] != 0.0) | (k[4] != 0.0) | (k[5] != 0.0) | (k[6] != 0.0) | (k[7] != 0.0);
+}
+
+// ---- no-distortion scoring with a single-precision first tier -------------------------------------------------------
+// The division-free test above costs 18 double-precision instructions per (hypothesis, point); double precision occupies the
+// whole vector ALU (4 cycles per wave instruction, nothing else issues beside it), whereas v_fma/add/mul_f32 issue at twice
+// that rate and share the SIMD with the integer work of the extract kernels on the other streams (tools/ubench, profiles/r03_*).
+// So the sign of  e = A^2 + B^2 - pz^2  is first formed in f32 from f32-rounded copies of the same inputs, together with a
+// rigorous bound m on |e32 - e*| (e* = the value in exact arithmetic on the double inputs):
+//   * a dot product fma(r0, X, fma(r1, Y, fma(r2, Z, r3))) of rounded inputs is within 5.01 u S of the exact one,
+//     S = |r0 X| + |r1 Y| + |r2 Z| + |r3|,  u = 2^-24 (two input roundings and at most three fma roundings per term);
+//   * A32 = fma(-oc32, pz32, px32) is within 7.1 u (Sx + |oc| Sz) of A*;  E = 8.5 u (Sxb + (ocm + 1) Szb) bounds the error of
+//     A32, B32 and pz32 alike, with Sxb = rho_x nu + tau_x >= Sx, Sy and Szb = rho_z nu + tau_z >= Sz formed once per
+//     (hypothesis, lane) from per-hypothesis row norms and the lane's largest |X|+|Y|+|Z| and |oc| (all rounded up);
+//   * |e32 - e*| <= 2 E s + 3 E^2 + 3.01 u s^2  with  s = |A32| + |B32| + |pz32|.
+// m = s (2.02 E + 32 u s) + 3.1 E^2 leaves 1.7e-6 s^2 >= 1.7e-6 pz^2 beyond that, so a pair decided here (|e32| > m, and
+// |pz32| >= 1.01 zg + E, the double test's guard against a vanishing depth) lies outside the double test's own 1e-6 shell with
+// the same sign: the count is the one the double test, and therefore the exact rule, gives.  Everything else -- about one
+// (hypothesis, point slot) in a hundred has such a lane -- takes the double-precision test for that slot, points reloaded.
+// NaN or infinite inputs fail every comparison and land there as well.
+__device__ __noinline__ unsigned long long pnp_slot_f64(const PnpArgs& a, const double* __restrict__ Xw, const double* __restrict__ x, int i,
+                                                           unsigned long long mask, const double* Rs, const double* Rt, double zg,
+                                                           double fx, double fy, double cx, double cy, double inv_thr, double eps)
+{
+    // the double-precision division-free test of pnp_score_body<false> for ONE point slot, lanes outside `mask` ignored
+    const double X = Xw[3 * i], Y = Xw[3 * i + 1], Z = Xw[3 * i + 2], ox = x[2 * i], oy = x[2 * i + 1];
+    const double ocx = (ox - cx) * inv_thr, ocy = (oy - cy) * inv_thr;
+    const double pxs = fma(Rs[0], X, fma(Rs[1], Y, fma(Rs[2], Z, Rs[3])));
+    const double pys = fma(Rs[4], X, fma(Rs[5], Y, fma(Rs[6], Z, Rs[7])));
+    const double pz = fma(Rt[8], X, fma(Rt[9], Y, fma(Rt[10], Z, Rt[11])));
+    const double A = fma(-ocx, pz, pxs), Bv = fma(-ocy, pz, pys);
+    const double pz2 = pz * pz;
+    const double e = fma(A, A, fma(Bv, Bv, -pz2));
+    const double m = eps * pz2;
+    const unsigned long long un = (__builtin_amdgcn_ballot_w64(!(fabs(e) > m)) | __builtin_amdgcn_ballot_w64(fabs(pz) < zg)) & mask;
+    unsigned long long in = __builtin_amdgcn_ballot_w64(e < -m) & mask & ~un;
+    if (un) { // wave-uniform, rare: the exact cvProjectPoints2 evaluation (same operations as project_pt)
+        const double px = fma(Rt[0], X, fma(Rt[1], Y, fma(Rt[2], Z, Rt[3])));
+        const double py = fma(Rt[4], X, fma(Rt[5], Y, fma(Rt[6], Z, Rt[7])));
+        const double z = pz ? 1. / pz : 1;
+        const double u = fma(px * z, fx, cx), v = fma(py * z, fy, cy);
+        const double dx = ox - u, dy = oy - v;
+        in |= __builtin_amdgcn_ballot_w64(fma(dx, dx, dy * dy) < a.thr2cut) & un;
+    }
+    return in;
+}
+
+struct PnpModel32 { float r[12]; float rho_x, tau_x, rho_z, tau_z, tn; };
+constexpr int PNP32_PT = 8;       // points per lane of the f32 kernel
+constexpr int PNP_WQCAP = 1024;   // undecided pairs a wavefront can queue per pass over its points (a few dozen are, at the bench sizes)   // rows 0/1 scaled (threshold units), row 2, bounds
+
+__device__ __forceinline__ void pnp_score_body_f32(const PnpArgs& a, int b, int h0, int nh, int tid, int lane, const double (*s_Rt)[12],
+                                                   const double (*s_Rs)[8], const double* s_tn, const PnpModel32* s_m32, const int* s_valid, int* s_cnt, uint32_t* wq)
+{
+    const int P = a.P[b];
+    const double* K = a.K + b * 9;
+    const double fx = K[0], fy = K[4], cx = K[2], cy = K[5];
+    const double* Xw = a.X + (size_t)b * a.capP * 3;
+    const double* x = a.x + (size_t)b * a.capP * 2;
+    const double inv_thr = 1.0 / a.thr;
+    const bool thr_ok = a.thr >= 1e-3 && a.thr <= 1e6;
+    const double eps = thr_ok ? 1e-6 : __longlong_as_double(0x7ff0000000000000ll);
+    const double sf = (fabs(fx) > fabs(fy) ? fabs(fx) : fabs(fy)) * inv_thr;
+    const float UP = 1.0f + 0x1p-20f;                       // a rounded-to-nearest float times UP is >= the value it was rounded from
+    const float sf32 = (float)sf * UP;
+    constexpr float CE = 8.5f * 0x1p-24f, C2 = 32.5f * 0x1p-24f;
+    for (int c0 = 0; c0 < P; c0 += SCORE_THREADS * PNP32_PT) {
+        float X[PNP32_PT], Y[PNP32_PT], Z[PNP32_PT], ocx[PNP32_PT], ocy[PNP32_PT];
+        unsigned long long livem[PNP32_PT];
+        double nrm = 0.0;
+        float ocm = 0.f;
+        int wn = 0;   // entries in this wavefront's queue (wave-uniform)
+#pragma unroll
+        for (int j = 0; j < PNP32_PT; j++) {
+            const int i = c0 + j * SCORE_THREADS + tid;
+            const bool live = i < P;
+            livem[j] = __builtin_amdgcn_ballot_w64(live);
+            const int ic = live ? i : 0;
+            const double Xd = Xw[3 * ic], Yd = Xw[3 * ic + 1], Zd = Xw[3 * ic + 2];
+            const double ocxd = (x[2 * ic] - cx) * inv_thr, ocyd = (x[2 * ic + 1] - cy) * inv_thr;
+            // A lane without a point gets one that every hypothesis rejects with certainty (an observation 1e15 thresholds away:
+            // e ~ 1e30 pz^2 is far outside the shell, never an inlier), so the hot loop needs no liveness mask; if pz vanishes the
+            // slot takes the double test, which masks by liveness.
+            X[j] = live ? (float)Xd : 0.f; Y[j] = live ? (float)Yd : 0.f; Z[j] = live ? (float)Zd : 0.f;
+            ocx[j] = live ? (float)ocxd : 1e15f; ocy[j] = live ? (float)ocyd : 1e15f;
+            if (live) {
+                nrm = fmax(nrm, fabs(Xd) + fabs(Yd) + fabs(Zd));   // the double test's own quantity (its zg uses it)
+                ocm = fmaxf(ocm, fmaxf(fabsf(ocx[j]), fabsf(ocy[j])));
+            }
+        }
+        const float nu = (float)nrm * UP;
+        ocm = ocm * UP + 1.0f;
+        // the f32 tier needs a sane dynamic range: otherwise every slot takes the double test (an infinite depth guard does that)
+        const bool tier_ok = thr_ok && sf32 < 1e15f && __builtin_amdgcn_ballot_w64(!(nu < 1e15f && ocm < 1e15f)) == 0;   // wave-uniform
+        const float guard_scale = tier_ok ? 1.01e-7f * sf32 : __builtin_inff();
+        // the hypotheses to score as a mask in a scalar register (no LDS round trip per hypothesis to learn that it has a pose)
+        unsigned vmask = (unsigned)__builtin_amdgcn_ballot_w64(lane < nh && s_valid[lane & (PNP_HPB - 1)] != 0);
+        while (vmask) {
+            const int q = __builtin_ctz(vmask);
+            vmask &= vmask - 1;
+            const PnpModel32& M = s_m32[q];
+            float r[12];
+#pragma unroll
+            for (int e = 0; e < 12; e++) r[e] = M.r[e];
+            // error bound of A32, B32, pz32 for this (hypothesis, lane), and the depth guard
+            const float Sxb = fmaf(M.rho_x, nu, M.tau_x), Szb = fmaf(M.rho_z, nu, M.tau_z);
+            const float E = CE * fmaf(ocm, Szb, Sxb);
+            const float twoE = 2.02f * E, E2 = 3.1f * E * E;
+            const float zg32 = fmaf(guard_scale, nu + M.tn, E) + 1e-30f;
+            int cnt = 0;
+            unsigned long long um[PNP32_PT], inm[PNP32_PT], any = 0;
+            float pzmin = __builtin_inff();
+#pragma unroll
+            for (int j = 0; j < PNP32_PT; j++) {
+                const float pz = fmaf(r[8], X[j], fmaf(r[9], Y[j], fmaf(r[10], Z[j], r[11])));
+                const float px = fmaf(r[0], X[j], fmaf(r[1], Y[j], fmaf(r[2], Z[j], r[3])));
+                const float py = fmaf(r[4], X[j], fmaf(r[5], Y[j], fmaf(r[6], Z[j], r[7])));
+                const float A = fmaf(-ocx[j], pz, px), Bv = fmaf(-ocy[j], pz, py);
+                const float e = fmaf(A, A, fmaf(Bv, Bv, -(pz * pz)));
+                const float s = fabsf(A) + fabsf(Bv) + fabsf(pz);
+                const float m = fmaf(s, fmaf(C2, s, twoE), E2);
+                // scalar-unit work per pair kept to a popcount, an add and an or: the scalar unit serves all four SIMDs of the CU
+                um[j] = __builtin_amdgcn_ballot_w64(!(fabsf(e) > m));
+                inm[j] = __builtin_amdgcn_ballot_w64(e < -m);
+                cnt += __popcll(inm[j]);
+                any |= um[j];
+                pzmin = fminf(pzmin, fabsf(pz));   // the depth guard is checked once per hypothesis (v_min3 folds two points per instruction)
+            }
+            {   // depth guard: rare (pz is metres in front of the camera), so it is checked once per hypothesis on the lane's smallest
+                // |pz| and the slots it concerns are found again only then (a lane without a point has pz = t_z, which may be small)
+                if (__builtin_amdgcn_ballot_w64(!(pzmin >= zg32))) {
+#pragma unroll
+                    for (int j = 0; j < PNP32_PT; j++) {
+                        const float pz = fmaf(r[8], X[j], fmaf(r[9], Y[j], fmaf(r[10], Z[j], r[11])));
+                        const unsigned long long g = __builtin_amdgcn_ballot_w64(!(fabsf(pz) >= zg32)) & livem[j];
+                        um[j] |= g; any |= g;
+                    }
+                }
+            }
+            if (any && a.f32_tier != 2) { // wave-uniform (2: timing probe without the second tier)
+                // undecided (hypothesis, point) pairs go to this wavefront's queue (its own region of LDS and a count in a scalar
+                // register: no atomics, no barrier) and are decided in double precision on dense lanes after the hypothesis loop;
+                // a full queue (inputs far outside anything a camera produces) decides the slot at once
+#pragma unroll
+                for (int j = 0; j < PNP32_PT; j++) {
+                    const unsigned long long mask = um[j] & livem[j];
+                    if (!mask) continue;
+                    cnt -= __popcll(inm[j] & um[j]);
+                    const int n = __popcll(mask);
+                    if (wn + n <= PNP_WQCAP) {
+                        const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+                        if (__builtin_amdgcn_inverse_ballot_w64(mask)) wq[wn + rank] = (uint32_t)q << 16 | (uint32_t)(j * SCORE_THREADS + tid);
+                        wn += n;
+                    } else {
+                        const double zg = 1e-7 * sf * (nrm + s_tn[q]) + 1e-300;
+                        const int i = c0 + j * SCORE_THREADS + tid;
+                        cnt += __popcll(pnp_slot_f64(a, Xw, x, i < P ? i : 0, mask, s_Rs[q], s_Rt[q], zg, fx, fy, cx, cy, inv_thr, eps));
+                    }
+                }
+            }
+            if (lane == 0) atomicAdd(&s_cnt[q], cnt);
+        }
+        // ---- second tier: this wavefront's queued pairs, one per lane, by the double-precision division-free test (and the exact
+        // rule inside its shell); LDS operations of one wavefront complete in order, so its own queue writes are visible to it
+        for (int k0 = 0; k0 < wn; k0 += 64) {
+            const int k = k0 + lane;
+            const bool on = k < wn;
+            const uint32_t ent = on ? wq[k] : 0u;
+            const int q = (int)(ent >> 16), i = c0 + (int)(ent & 0xFFFFu);
+            const double* Rs = s_Rs[q];   // per-lane hypothesis
+            const double* Rt = s_Rt[q];
+            const int ic = on ? i : 0;
+            const double Xd = Xw[3 * ic], Yd = Xw[3 * ic + 1], Zd = Xw[3 * ic + 2], ox = x[2 * ic], oy = x[2 * ic + 1];
+            const double ocxd = (ox - cx) * inv_thr, ocyd = (oy - cy) * inv_thr;
+            const double zg = 1e-7 * sf * (fabs(Xd) + fabs(Yd) + fabs(Zd) + s_tn[q]) + 1e-300;   // the guard with the point's own norm
+            const double pxs = fma(Rs[0], Xd, fma(Rs[1], Yd, fma(Rs[2], Zd, Rs[3])));
+            const double pys = fma(Rs[4], Xd, fma(Rs[5], Yd, fma(Rs[6], Zd, Rs[7])));
+            const double pz = fma(Rt[8], Xd, fma(Rt[9], Yd, fma(Rt[10], Zd, Rt[11])));
+            const double A = fma(-ocxd, pz, pxs), Bv = fma(-ocyd, pz, pys);
+            const double pz2 = pz * pz;
+            const double e = fma(A, A, fma(Bv, Bv, -pz2));
+            const double m = eps * pz2;
+            bool in;
+            if (!(fabs(e) > m) || fabs(pz) < zg) {   // the exact cvProjectPoints2 evaluation (same operations as project_pt)
+                const double px = fma(Rt[0], Xd, fma(Rt[1], Yd, fma(Rt[2], Zd, Rt[3])));
+                const double py = fma(Rt[4], Xd, fma(Rt[5], Yd, fma(Rt[6], Zd, Rt[7])));
+                const double z = pz ? 1. / pz : 1;
+                const double u = fma(px * z, fx, cx), v = fma(py * z, fy, cy);
+                const double dx = ox - u, dy = oy - v;
+                in = fma(dx, dx, dy * dy) < a.thr2cut;
+            } else {
+                in = e < -m;
+            }
+            if (on && in) atomicAdd(&s_cnt[q], 1);
+        }
+    }
+}
+
 __global__ __launch_bounds__(SCORE_THREADS)
 void pnp_score_k(PnpArgs a)
 {
     const int b = blockIdx.y, h0 = blockIdx.x * PNP_HPB, tid = threadIdx.x, lane = tid & 63;
     const int nh = min(PNP_HPB, a.H - h0);
+    if (a.f32_tier && !pnp_has_dist(a.dist + b * 8)) return;   // pnp_score32_k scores this problem
     __shared__ double s_Rt[PNP_HPB][12];
     __shared__ double s_Rs[PNP_HPB][8]; // rows 0/1 scaled by fx/thr, fy/thr (division-free test only)
     __shared__ double s_tn[PNP_HPB];
@@ -1123,10 +1325,59 @@ void pnp_score_k(PnpArgs a)
         s_tn[tid] = fabs(s_Rt[tid][3]) + fabs(s_Rt[tid][7]) + fabs(s_Rt[tid][11]);
     }
     __syncthreads();
-    const double* k = a.dist + b * 8;
-    const bool has_dist = (k[0] != 0.0) | (k[1] != 0.0) | (k[2] != 0.0) | (k[3] != 0.0) | (k[4] != 0.0) | (k[5] != 0.0) | (k[6] != 0.0) | (k[7] != 0.0);
-    if (has_dist) pnp_score_body<true>(a, b, h0, nh, tid, lane, s_Rt, s_Rs, s_tn, s_valid, s_cnt);
+    if (pnp_has_dist(a.dist + b * 8)) pnp_score_body<true>(a, b, h0, nh, tid, lane, s_Rt, s_Rs, s_tn, s_valid, s_cnt);
     else pnp_score_body<false>(a, b, h0, nh, tid, lane, s_Rt, s_Rs, s_tn, s_valid, s_cnt);
+    __syncthreads();
+    if (tid < nh) a.counts[(size_t)b * a.H + h0 + tid] = s_valid[tid] ? s_cnt[tid] : 0;
+}
+
+// The no-distortion problems of the batch with the single-precision first tier (a kernel of its own: the double bodies above need
+// 168 VGPRs, this one fits four wavefronts per SIMD, which the paired issue of its f32 instructions needs).
+__global__ __launch_bounds__(SCORE_THREADS, 4)
+void pnp_score32_k(PnpArgs a)
+{
+    const int b = blockIdx.y, h0 = blockIdx.x * PNP_HPB, tid = threadIdx.x, lane = tid & 63;
+    const int nh = min(PNP_HPB, a.H - h0);
+    if (pnp_has_dist(a.dist + b * 8)) return;   // pnp_score_k scores this problem
+    __shared__ double s_Rt[PNP_HPB][12];
+    __shared__ double s_Rs[PNP_HPB][8];
+    __shared__ double s_tn[PNP_HPB];
+    __shared__ int s_cnt[PNP_HPB];
+    __shared__ int s_valid[PNP_HPB];
+    __shared__ PnpModel32 s_m32[PNP_HPB];
+    __shared__ uint32_t s_queue[SCORE_THREADS / 64][PNP_WQCAP];
+    {
+        const double* K = a.K + b * 9;
+        const double sfx = K[0] / a.thr, sfy = K[4] / a.thr;
+        for (int i = tid; i < PNP_HPB * 12; i += SCORE_THREADS) {
+            const int hh = i / 12, e = i % 12;
+            const double v = (hh < nh) ? a.models[((size_t)b * a.H + h0 + hh) * 12 + e] : 0.0;
+            s_Rt[hh][e] = v;
+            if (e < 8) s_Rs[hh][e] = v * (e < 4 ? sfx : sfy);
+        }
+    }
+    if (tid < PNP_HPB) s_cnt[tid] = 0;
+    __syncthreads();
+    if (tid < PNP_HPB) {
+        s_valid[tid] = !(s_Rt[tid][8] == 0.0 && s_Rt[tid][9] == 0.0 && s_Rt[tid][10] == 0.0);
+        s_tn[tid] = fabs(s_Rt[tid][3]) + fabs(s_Rt[tid][7]) + fabs(s_Rt[tid][11]);
+        // single-precision copy of the model and the row norms its error bound is made of (rounded up)
+        const float UP = 1.0f + 0x1p-20f;
+        PnpModel32 M;
+#pragma unroll
+        for (int e = 0; e < 8; e++) M.r[e] = (float)s_Rs[tid][e];
+#pragma unroll
+        for (int e = 8; e < 12; e++) M.r[e] = (float)s_Rt[tid][e];
+        const double* R = s_Rs[tid];
+        M.rho_x = (float)fmax(fmax(fmax(fabs(R[0]), fabs(R[1])), fabs(R[2])), fmax(fmax(fabs(R[4]), fabs(R[5])), fabs(R[6]))) * UP;
+        M.tau_x = (float)fmax(fabs(R[3]), fabs(R[7])) * UP;
+        M.rho_z = (float)fmax(fmax(fabs(s_Rt[tid][8]), fabs(s_Rt[tid][9])), fabs(s_Rt[tid][10])) * UP;
+        M.tau_z = (float)fabs(s_Rt[tid][11]) * UP;
+        M.tn = (float)s_tn[tid] * UP;
+        s_m32[tid] = M;
+    }
+    __syncthreads();
+    pnp_score_body_f32(a, b, h0, nh, tid, lane, s_Rt, s_Rs, s_tn, s_m32, s_valid, s_cnt, s_queue[tid >> 6]);
     __syncthreads();
     if (tid < nh) a.counts[(size_t)b * a.H + h0 + tid] = s_valid[tid] ? s_cnt[tid] : 0;
 }
@@ -1535,12 +1786,16 @@ int mslam_pnp_ransac_batch_dev(mslam_ctx* ctx, const double* X, const double* x,
     a.X = X; a.x = x; a.P = P; a.capP = capP; a.K = K; a.dist = dist; a.samples = samples; a.H = H; a.B = B;
     a.thr = prm->reproj_thr; a.thr2cut = sqrt_cut(prm->reproj_thr); a.confidence = prm->confidence;
     a.refine_iters = prm->refine_iters; a.min_inliers = prm->min_inliers;
+    static const int f32_tier = [] { const char* e = getenv("MSLAM_PNP_F32"); return e ? atoi(e) : 1; }();
+    a.f32_tier = f32_tier;
     a.xn = (double*)(base + o_xn); a.models = (double*)(base + o_mod);
     a.counts = inlier_counts ? inlier_counts : (int32_t*)(base + o_cnt);
     a.best = best_h; a.best_cnt = (int32_t*)(base + o_bc);
     a.Rt = Rt; a.rvec = rvec; a.tvec = tvec; a.inliers = inliers; a.n_inliers = n_inliers; a.status = nullptr;
     LAUNCH(ctx, K_PNP_PREPARE, pnp_prepare_k, dim3((capP + 255) / 256, B), dim3(256), 0, a);
     LAUNCH(ctx, K_PNP_SOLVE, pnp_solve_k, dim3((H + 63) / 64, B), dim3(64), 0, a);
+    // each of the two scoring kernels leaves at once the problems the other one owns (distortion or not is device data)
+    if (a.f32_tier) LAUNCH(ctx, K_PNP_SCORE32, pnp_score32_k, dim3((H + PNP_HPB - 1) / PNP_HPB, B), dim3(SCORE_THREADS), 0, a);
     LAUNCH(ctx, K_PNP_SCORE, pnp_score_k, dim3((H + PNP_HPB - 1) / PNP_HPB, B), dim3(SCORE_THREADS), 0, a);
     LAUNCH(ctx, K_RANSAC_SELECT, ransac_select_k, dim3(B), dim3(64), 0, a.counts, P, H, 4, prm->confidence, best_h, a.best_cnt, 0, H, (int32_t*)nullptr);
     LAUNCH(ctx, K_PNP_FINALIZE, pnp_finalize_k, dim3(B), dim3(FIN_THREADS), 0, a);

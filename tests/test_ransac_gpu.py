@@ -223,6 +223,66 @@ def test_pnp_threshold_shell_and_camera_plane(ctx, oracle):
     np.testing.assert_array_equal(g["inliers"], o["inliers"])
 
 
+@pytest.mark.parametrize("scale,thr,f", [(1.0, 2.0, 1.0), (1e-3, 2.0, 1.0), (1e3, 2.0, 1.0), (1e6, 0.5, 1.0), (1.0, 0.01, 1.0), (1.0, 50.0, 1.0),
+                                         (1.0, 2.0, 40.0), (1e-6, 8.0, 0.05), (1.0, 2e-4, 1.0), (1.0, 5e6, 1.0)])
+def test_pnp_single_precision_tier_over_scales(ctx, oracle, scale, thr, f):
+    """pnp_score32_k decides most (hypothesis, point) pairs in single precision under a rigorous error bound and hands the
+    rest to the double-precision test.  The bound is made of magnitudes (world scale, focal length / threshold, distance of the
+    observation from the principal point), so the counts must stay identical to the oracle's when those vary by orders of
+    magnitude; observations sit on the threshold circle of the true pose at relative distances from 1e-9 to 1e-2, where the
+    single-precision shell is crossed.  A threshold outside [1e-3, 1e6] switches the tier off (every pair by the exact rule)."""
+    K = synth.K_MINITAUR.copy(); K[0, 0] *= f; K[1, 1] *= f
+    pr = synth.pnp_problem(900, 77, K=K, noise=0.3, outlier_frac=0.3)
+    X, x, R, t = pr["X"] * scale, pr["x"].copy(), pr["R"], pr["tvec"] * scale
+    rng = np.random.default_rng(11)
+    good = np.flatnonzero(~pr["outlier"])
+    deltas = np.array([1e-9, -1e-9, 1e-7, -1e-7, 1e-6, -1e-6, 1e-5, -1e-5, 1e-4, -1e-4, 1e-3, -1e-3, 1e-2, -1e-2])
+    for n, i in enumerate(good[:280]):
+        a = rng.uniform(0, 2 * np.pi)
+        Xc = R @ X[i] + t
+        proj = np.array([K[0, 0] * Xc[0] / Xc[2] + K[0, 2], K[1, 1] * Xc[1] / Xc[2] + K[1, 2]])
+        x[i] = proj + thr * (1 + deltas[n % len(deltas)]) * np.array([np.cos(a), np.sin(a)])
+    S = synth.sample_table(900, 700, 4, 13)
+    S[:64] = rng.permutation(good[280:])[:256].reshape(64, 4)   # all-inlier samples: poses next to the truth
+    p = api.default_pnp_params()
+    p.reproj_thr, p.confidence = thr, 0.0
+    try:
+        g = ctx.pnp_ransac(X, x, K, pr["dist"], S, p)
+    except api.MslamError as e:
+        g = dict(rc=e.status)
+    o = oracle.pnp_ransac(X, x, K, pr["dist"], S, _pp(oracle, p))
+    assert g["rc"] == o["rc"]
+    if g["rc"] == 0:
+        np.testing.assert_array_equal(g["counts"], o["counts"])
+        np.testing.assert_array_equal(g["inliers"], o["inliers"])
+        assert g["best_h"] == o["best_h"]
+
+
+def test_pnp_double_precision_scoring_alone(oracle):
+    """MSLAM_PNP_F32=0 keeps the double-precision division-free test as the only tier (the environment is read once per process)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import sys, numpy as np
+sys.path.insert(0, sys.argv[1])
+from monocular_slam_amd import api, synth
+from oracle import binding as ob
+pr = synth.pnp_problem(700, 5)
+S = synth.sample_table(700, 600, 4, 6)
+p = api.default_pnp_params(); p.reproj_thr = 2.0
+op = ob.pnp_default_params(); op.reproj_thr = 2.0
+with api.Context(0, 640, 480, 2048, 1) as ctx:
+    g = ctx.pnp_ransac(pr["X"], pr["x"], pr["K"], pr["dist"], S, p)
+    ctx.profile_enable(16); ctx.pnp_ransac(pr["X"], pr["x"], pr["K"], pr["dist"], S, p); names = set(ctx.profile_read())
+o = ob.pnp_ransac(pr["X"], pr["x"], pr["K"], pr["dist"], S, op)
+assert (g["counts"] == o["counts"]).all() and g["best_h"] == o["best_h"]
+assert "pnp_score32_k" not in names and "pnp_score_k" in names, names
+print("f64 ok")
+"""
+    r = subprocess.run([sys.executable, "-c", code, root], env=dict(os.environ, MSLAM_PNP_F32="0"), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "f64 ok" in r.stdout, r.stdout + r.stderr
+
+
 def test_fmat_threshold_shell(ctx, oracle):
     """Matches displaced from their epipolar line by sqrt(thr) * (1 +- tiny): counts and masks still bit-exact."""
     tv = synth.two_view_problem(400, 31, noise=0.0, outlier_frac=0.1)
