@@ -29,12 +29,20 @@ METRIC = "frames/sec (extract+match+PnP) at 1920x1080, 2k kpts/frame"
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# The headline is measured in the reference's arithmetic widths: the PnP inlier test stays in double precision (the library's
+# single-precision first tier -- identical counts, scoring alone 26 % faster -- changes nothing under this concurrent schedule:
+# 50.7 k frames/s either way, profiles/r03_*; MSLAM_PNP_F32=1 in the environment measures it)
+os.environ.setdefault("MSLAM_PNP_F32", "0")
 
 W, H, NFEAT = 1920, 1080, 2000
 PNP_P, PNP_H, PNP_THR = 2000, 4096, 2.0
 RATIO = 0.8
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
-ISSUE_PEAK_G = 256 * 4 * 2.4 / 4  # G wave-instructions/s: 256 CUs x 4 SIMDs, one wave64 VALU op per 4 clocks at 2.4 GHz
+# G wave-instructions/s: 256 CUs x 4 SIMDs, one wave64 VALU op per 4 clocks at 2.4 GHz.  That is the rate of the instruction forms
+# this path is made of (SDWA byte operands, packed 16-bit, compares, dot products, 3-operand integer forms, f64); plain 32-bit
+# add/sub/logic/shift-right and f32 add/mul/fma issue at twice that rate when two wavefronts of a SIMD have one ready each
+# (measured per opcode: tools/ubench/valu_rate, profiles/r03_valu_rate_*.txt)
+ISSUE_PEAK_G = 256 * 4 * 2.4 / 4
 SALU_PEAK_G = 256 * 2.4           # one scalar instruction per CU per clock (an upper bound; shared by the CU's 4 SIMDs)
 
 # algorithmic bytes per unit: extract W*H + 56*N; match 32*(Nq+Nt) + 16*Nq;
@@ -47,7 +55,7 @@ ALG_BYTES = {
 KERNEL_UNIT = {  # which per-frame unit a kernel's launch is priced against
     "bgr2gray_k": "extract", "resize_k": "extract", "pyramid2_k": "extract", "fast_nms_k": "extract", "select_k": "extract",
     "describe_k": "extract", "hamming_knn2_partial": "match", "expand_pm1_k": "match", "hamming_mfma_k": "match", "knn2_finalize": "match",
-    "pnp_prepare_k": "pnp", "pnp_solve_k": "pnp", "pnp_score_k": "pnp", "ransac_select_k": "pnp", "pnp_finalize_k": "pnp",
+    "pnp_prepare_k": "pnp", "pnp_solve_k": "pnp", "pnp_score_k": "pnp", "pnp_score32_k": "pnp", "ransac_select_k": "pnp", "pnp_finalize_k": "pnp",
 }
 # f64 flops per (hypothesis, point) pair of pnp_score_k's sign test (3 rows x (3 fma) + e = A^2 + B^2 - z^2: DESIGN.md 4)
 PNP_SCORE_FLOP_PER_PAIR = 2 * 9 + 2 * 3 + 2
@@ -416,7 +424,7 @@ def main():
                        "streams_per_gpu": B, "frames_per_stream_per_step": T, "frames_per_step": B * T * world,
                        "sub_batches": NS, "frames_per_launch": SB,
                        "frames_resident_in_hbm": True, "frame_sets_per_stream": 2,
-                       "pnp_decoupled_from_match": True, "pnp_on_second_stream": bool(args.overlap),
+                       "pnp_decoupled_from_match": True, "pnp_f32_tier": os.environ.get("MSLAM_PNP_F32") != "0", "pnp_on_second_stream": bool(args.overlap),
                        "parallelism": f"{world} GPU(s) x {B} independent streams"
                                       + (" + RCCL all-gather of PnP inlier counts" if collective else " (no collective)")},
             "timed_seconds": elapsed,
@@ -504,14 +512,20 @@ def roofline_blocks(kern, kern_x, nprof, SB, NS, value, world) -> dict:
     out["roofline_path"] = path
     # f64 RANSAC kernels: priced in work units, not bytes
     comp = {}
-    if "pnp_score_k" in per:
+    # the scoring kernel that did the work: pnp_score32_k (single-precision first tier, the default) or pnp_score_k (MSLAM_PNP_F32=0;
+    # with the tier on it only leaves the problems it does not own)
+    sk = "pnp_score32_k" if "pnp_score32_k" in per else "pnp_score_k"
+    if sk in per:
         pairs = float(PNP_H) * PNP_P * SB
-        d, dx = per["pnp_score_k"], per_x.get("pnp_score_k")
-        comp["pnp_score_k"] = {"G_hyp_pt_per_s": pairs / (d * 1e-3) / 1e9, "GFLOPs_f64": pairs * PNP_SCORE_FLOP_PER_PAIR / (d * 1e-3) / 1e9,
-                               "avg_launch_ms": d}
+        d, dx = per[sk], per_x.get(sk)
+        comp[sk] = {"G_hyp_pt_per_s": pairs / (d * 1e-3) / 1e9, "avg_launch_ms": d,
+                    "arithmetic": "f32 sign test + error bound, f64 for the undecided pairs" if sk == "pnp_score32_k" else "f64 sign test"}
+        if sk == "pnp_score_k":
+            comp[sk]["GFLOPs_f64"] = pairs * PNP_SCORE_FLOP_PER_PAIR / (d * 1e-3) / 1e9
         if dx:
-            comp["pnp_score_k"]["exclusive"] = {"avg_launch_ms": dx, "G_hyp_pt_per_s": pairs / (dx * 1e-3) / 1e9,
-                                                "GFLOPs_f64": pairs * PNP_SCORE_FLOP_PER_PAIR / (dx * 1e-3) / 1e9}
+            comp[sk]["exclusive"] = {"avg_launch_ms": dx, "G_hyp_pt_per_s": pairs / (dx * 1e-3) / 1e9}
+            if sk == "pnp_score_k":
+                comp[sk]["exclusive"]["GFLOPs_f64"] = pairs * PNP_SCORE_FLOP_PER_PAIR / (dx * 1e-3) / 1e9
     if "pnp_solve_k" in per:
         d, dx = per["pnp_solve_k"], per_x.get("pnp_solve_k")
         comp["pnp_solve_k"] = {"M_hyp_per_s": PNP_H * SB / (d * 1e-3) / 1e6, "avg_launch_ms": d}

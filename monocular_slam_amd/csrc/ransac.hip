@@ -1297,7 +1297,7 @@ __device__ __forceinline__ void pnp_score_body_f32(const PnpArgs& a, int b, int 
     }
 }
 
-__global__ __launch_bounds__(SCORE_THREADS)
+__global__ __launch_bounds__(SCORE_THREADS, 3)   // three wavefronts per SIMD (168 VGPRs): two more registers would leave two
 void pnp_score_k(PnpArgs a)
 {
     const int b = blockIdx.y, h0 = blockIdx.x * PNP_HPB, tid = threadIdx.x, lane = tid & 63;
@@ -1786,8 +1786,7 @@ int mslam_pnp_ransac_batch_dev(mslam_ctx* ctx, const double* X, const double* x,
     a.X = X; a.x = x; a.P = P; a.capP = capP; a.K = K; a.dist = dist; a.samples = samples; a.H = H; a.B = B;
     a.thr = prm->reproj_thr; a.thr2cut = sqrt_cut(prm->reproj_thr); a.confidence = prm->confidence;
     a.refine_iters = prm->refine_iters; a.min_inliers = prm->min_inliers;
-    static const int f32_tier = [] { const char* e = getenv("MSLAM_PNP_F32"); return e ? atoi(e) : 1; }();
-    a.f32_tier = f32_tier;
+    { const char* e = getenv("MSLAM_PNP_F32"); a.f32_tier = e ? atoi(e) : 1; }   // read per call: a host can switch between calls
     a.xn = (double*)(base + o_xn); a.models = (double*)(base + o_mod);
     a.counts = inlier_counts ? inlier_counts : (int32_t*)(base + o_cnt);
     a.best = best_h; a.best_cnt = (int32_t*)(base + o_bc);

@@ -17,6 +17,7 @@ int main(int argc, char** argv)
 {
     int steps = 20, warmup = 3, B = 64, NS = 2, T = 16, w = 1920, h = 1080, nf = 2000, device = 0, P = 2000, H = 4096;
     double thr = 2.0;
+    setenv("MSLAM_PNP_F32", "0", 0);   // like bench.py: the headline keeps the PnP inlier test in double precision unless the caller's environment says otherwise
     for (int i = 1; i < argc; i++) {
         auto arg = [&](const char* n) { return !std::strcmp(argv[i], n) && i + 1 < argc; };
         if (arg("--steps")) steps = std::atoi(argv[++i]);

@@ -258,29 +258,24 @@ def test_pnp_single_precision_tier_over_scales(ctx, oracle, scale, thr, f):
         assert g["best_h"] == o["best_h"]
 
 
-def test_pnp_double_precision_scoring_alone(oracle):
-    """MSLAM_PNP_F32=0 keeps the double-precision division-free test as the only tier (the environment is read once per process)."""
-    import os, subprocess, sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = r"""
-import sys, numpy as np
-sys.path.insert(0, sys.argv[1])
-from monocular_slam_amd import api, synth
-from oracle import binding as ob
-pr = synth.pnp_problem(700, 5)
-S = synth.sample_table(700, 600, 4, 6)
-p = api.default_pnp_params(); p.reproj_thr = 2.0
-op = ob.pnp_default_params(); op.reproj_thr = 2.0
-with api.Context(0, 640, 480, 2048, 1) as ctx:
-    g = ctx.pnp_ransac(pr["X"], pr["x"], pr["K"], pr["dist"], S, p)
-    ctx.profile_enable(16); ctx.pnp_ransac(pr["X"], pr["x"], pr["K"], pr["dist"], S, p); names = set(ctx.profile_read())
-o = ob.pnp_ransac(pr["X"], pr["x"], pr["K"], pr["dist"], S, op)
-assert (g["counts"] == o["counts"]).all() and g["best_h"] == o["best_h"]
-assert "pnp_score32_k" not in names and "pnp_score_k" in names, names
-print("f64 ok")
-"""
-    r = subprocess.run([sys.executable, "-c", code, root], env=dict(os.environ, MSLAM_PNP_F32="0"), capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0 and "f64 ok" in r.stdout, r.stdout + r.stderr
+@pytest.mark.parametrize("use_dist", [False, True])
+def test_pnp_double_precision_scoring_alone(ctx, oracle, monkeypatch, use_dist):
+    """MSLAM_PNP_F32=0 (read at every call) keeps the double-precision division-free test as the only tier: same outputs, and
+    pnp_score32_k is not launched; with the tier on (the default) it is, and pnp_score_k only scores problems with distortion."""
+    pr = synth.pnp_problem(700, 5, K=synth.K_TUM1 if use_dist else synth.K_MINITAUR, dist=synth.DIST_TUM1 if use_dist else None,
+                           w=640 if use_dist else 1920, h=480 if use_dist else 1080)
+    S = synth.sample_table(700, 600, 4, 6)
+    p = api.default_pnp_params(); p.reproj_thr = 2.0
+    o = oracle.pnp_ransac(pr["X"], pr["x"], pr["K"], pr["dist"], S, _pp(oracle, p))
+    for mode in ("0", "1"):
+        monkeypatch.setenv("MSLAM_PNP_F32", mode)
+        ctx.profile_enable(16)
+        g = ctx.pnp_ransac(pr["X"], pr["x"], pr["K"], pr["dist"], S, p)
+        names = set(ctx.profile_read())
+        np.testing.assert_array_equal(g["counts"], o["counts"])
+        np.testing.assert_array_equal(g["inliers"], o["inliers"])
+        assert g["best_h"] == o["best_h"]
+        assert ("pnp_score32_k" in names) == (mode == "1") and "pnp_score_k" in names, (mode, names)
 
 
 def test_fmat_threshold_shell(ctx, oracle):
