@@ -1077,7 +1077,9 @@ void describe_k(OrbDev od, DescArgs out)
 {
     __shared__ uint32_t s_raw[DESC_WAVES][2 * DH_RP * DP_PITCH / 4 + 4];   // (+4: the last row's column groups read a dword past it)
     __shared__ uint32_t s_h[DESC_WAVES][4 * DH_CG * HT_DW];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // (the wavefront number as a scalar: the keypoint index and the level search below then run on the scalar unit -- as vector
+    // code the 16-level search was 85 of the kernel's ~730 vector instructions)
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const unsigned wg = xcd_contiguous(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y);
     const int b = (int)(wg / gridDim.x), bx = (int)(wg % gridDim.x);
     const int g = bx * DESC_WAVES + wave; // keypoint index inside the frame
