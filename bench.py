@@ -134,7 +134,8 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=64, help="independent streams per GPU")
-    ap.add_argument("--seq-len", type=int, default=16, help="consecutive frames per stream per step (a step = batch x seq-len frames)")
+    ap.add_argument("--seq-len", type=int, default=48, help="consecutive frames per stream per step (a step = batch x seq-len frames; 48: the driver's --steps 20 times more than a second)")
+    ap.add_argument("--no-ba", action="store_true", help="skip the BA build leg (roofline_ba: BASELINE configs[3], the path's HBM-bound kernel)")
     ap.add_argument("--sub-batches", type=int, default=2, help="the batch is enqueued as this many sub-batches on separate HIP streams")
     ap.add_argument("--cpu-frames", type=int, default=24, help="frames of the cpu_baseline sample (0 = skip)")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip the event-instrumented passes (roofline block)")
@@ -442,11 +443,42 @@ def main():
             out["ingest_inclusive"] = ingest
         if kern:
             out.update(roofline_blocks(kern, kern_x, NPROF, SB, NS, value, world))
+        if not args.no_ba and world == 1:
+            out["roofline_ba"] = ba_roofline(api, ctxs[0])
         if args.cpu_frames > 0 and world == 1:
             out["cpu_baseline"] = cpu_baseline(fr_a[0], fr_b[0], pnps[0], args.cpu_frames)
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+
+
+def ba_roofline(api, ctx, windows: int = 32, reps: int = 20) -> dict:
+    """BASELINE configs[3] (localBA residual/Jacobian build, 10 keyframes x 5000 map points, blocks to block-CSR), `windows`
+    independent windows per launch: the one kernel family of the path that streams.  Measured live with HIP events on the context's
+    stream, after the timed region (never part of `value`); algorithmic bytes = SURVEY 8d's 216 B per edge x the edges of a launch."""
+    from monocular_slam_amd import synth
+    pr = synth.ba_concat([synth.ba_problem(10, 5000, 4004 + i) for i in range(windows)])
+    plan = api.BaPlan(ctx, pr)
+    for _ in range(3):
+        plan.build_dev()
+    ctx.sync()
+    ctx.profile_enable(16 * reps)
+    for _ in range(reps):
+        plan.build_dev()
+    prof = {k: v[0] / max(1, v[1]) for k, v in ctx.profile_read().items()}
+    ctx.profile_enable(0)
+    plan.close()
+    E = int(pr["n_edges"])
+    alg = 216.0 * E
+    dom = max(prof, key=prof.get)
+    total = sum(prof.values())
+    return {"bound": "hbm", "kernel": dom, "achieved": alg / (prof[dom] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": alg / (prof[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+            "algorithmic_bytes_per_launch": alg, "avg_launch_ms": prof[dom], "edges_per_launch": E, "windows_per_launch": windows,
+            "whole_build": {"kernels_ms": {k: round(v, 5) for k, v in prof.items()}, "ms": total, "achieved": alg / (total * 1e-3) / 1e9,
+                            "frac": alg / (total * 1e-3) / 1e9 / HBM_PEAK_GBS, "window_builds_per_s": windows / (total * 1e-3)},
+            "workload": "BASELINE configs[3]: BA residual/Jacobian build, 10 keyframes x 5000 map points per window, J^T J blocks to block-CSR",
+            "note": "separate leg after the timed region, one stream, kernels alone on the chip; counter traffic of this kernel: profiles/r02_pmc_summary_ba_probe.json"}
 
 
 def roofline_blocks(kern, kern_x, nprof, SB, NS, value, world) -> dict:

@@ -7,7 +7,7 @@
 set -e
 OUT=${1:-gpurun_out/prof}
 shift || true
-ARGS=${@:---steps 3 --warmup 1 --cpu-frames 0 --no-ingest --no-parity}
+ARGS=${@:---steps 3 --warmup 1 --seq-len 16 --cpu-frames 0 --no-ingest --no-parity --no-ba}
 REPO=$(pwd)
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
