@@ -145,6 +145,19 @@ def main():
     ap.add_argument("--force-collective", action="store_true", help="rehearsal: create the RCCL communicator and all-gather at N = 1 too")
     args = ap.parse_args()
 
+    # stdout carries the one JSON line and nothing else: gloo ("[Gloo] Rank 0 is connected to ...") and RCCL (a version banner when
+    # the first communicator comes up) write to file descriptor 1 from native code, so the descriptor points at stderr until the
+    # line is printed
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(obj):
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
+        print(json.dumps(obj), flush=True)
+        os.dup2(2, 1)
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -233,8 +246,8 @@ def main():
                 # the creation thread may still finish later and would then share tbs[0].pnp_ctx's stream with the timed loop,
                 # and the peers may still be inside ncclCommInitRank: nothing measured after this point could be trusted.
                 # Report and leave (no in-process restart); the launcher ends the other ranks.
-                print(json.dumps({"metric": METRIC, "value": None, "unit": "frames/s", "n_gpus": world, "rank": rank,
-                                  "error": "RCCL communicator creation did not return within the watchdog time (BENCH_COMM_TIMEOUT)"}), flush=True)
+                emit({"metric": METRIC, "value": None, "unit": "frames/s", "n_gpus": world, "rank": rank,
+                      "error": "RCCL communicator creation did not return within the watchdog time (BENCH_COMM_TIMEOUT)"})
                 os._exit(3)
         else:
             box["err"] = uid_err or "no RCCL unique id"
@@ -447,7 +460,7 @@ def main():
             out["roofline_ba"] = ba_roofline(api, ctxs[0])
         if args.cpu_frames > 0 and world == 1:
             out["cpu_baseline"] = cpu_baseline(fr_a[0], fr_b[0], pnps[0], args.cpu_frames)
-        print(json.dumps(out))
+        emit(out)
     if dist is not None:
         dist.destroy_process_group()
 
