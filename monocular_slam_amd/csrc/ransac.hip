@@ -1116,9 +1116,13 @@ __device__ __forceinline__ bool pnp_has_dist(const double* k)
 //   * |e32 - e*| <= 2 E s + 3 E^2 + 3.01 u s^2  with  s = |A32| + |B32| + |pz32|.
 // m = s (2.02 E + 32 u s) + 3.1 E^2 leaves 1.7e-6 s^2 >= 1.7e-6 pz^2 beyond that, so a pair decided here (|e32| > m, and
 // |pz32| >= 1.01 zg + E, the double test's guard against a vanishing depth) lies outside the double test's own 1e-6 shell with
-// the same sign: the count is the one the double test, and therefore the exact rule, gives.  Everything else -- about one
-// (hypothesis, point slot) in a hundred has such a lane -- takes the double-precision test for that slot, points reloaded.
-// NaN or infinite inputs fail every comparison and land there as well.
+// the same sign: the count is the one the double test, and therefore the exact rule, gives.  Everything else -- about 0.15 % of
+// the pairs at the bench sizes, one (hypothesis, point slot) in ten holds such a lane -- is appended to the wavefront's own queue in
+// LDS (count in a scalar register) and decided after the hypothesis loop by the double-precision test, one pair per lane (its depth
+// guard then uses the point's own norm, which the guard's derivation is about; the per-lane maximum above is an upper bound of it).
+// NaN or infinite inputs fail every comparison and land there as well; a threshold outside [1e-3, 1e6] or magnitudes beyond 1e15
+// make the guard infinite, i.e. every pair goes to the second tier.  The depth guard itself is checked once per hypothesis on the
+// lane's smallest |pz| (v_min3, half an instruction per pair) and resolved per slot only when it fires.
 __device__ __noinline__ unsigned long long pnp_slot_f64(const PnpArgs& a, const double* __restrict__ Xw, const double* __restrict__ x, int i,
                                                            unsigned long long mask, const double* Rs, const double* Rt, double zg,
                                                            double fx, double fy, double cx, double cy, double inv_thr, double eps)
