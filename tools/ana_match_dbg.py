@@ -1,10 +1,15 @@
+#!/usr/bin/env python3
+"""Per-wavefront timeline of hamming_mfma_k from the stamps the library writes with MSLAM_MATCH_DEBUG=<file> (eighth call of the
+process): wavefront lifetimes, start times, concurrency over the kernel's span, wavefronts per CU.
+
+usage: MSLAM_MATCH_DEBUG=gpurun_out/match_dbg.txt python tools/match_probe.py && python tools/ana_match_dbg.py gpurun_out/match_dbg.txt"""
 import sys, numpy as np
 d = np.loadtxt(sys.argv[1], dtype=np.uint64)
 t0, t1, flag, hw = d[:,1].astype(np.int64), d[:,2].astype(np.int64), d[:,3], d[:,4]
 act = (flag & 1) == 1
 xcc = (flag >> 8) & 0xF
-base = t0.min()
-print("waves", len(d), "active", act.sum(), "span (100MHz ticks)", (t1.max()-base), "=", (t1.max()-base)/100.0, "us")
+base = t0[act].min()
+print("waves", len(d), "active", act.sum(), "span (100 MHz ticks)", (t1[act].max()-base), "=", (t1[act].max()-base)/100.0, "us")
 life = (t1-t0)[act]/100.0
 print("active wave life us: mean %.2f p10 %.2f p50 %.2f p90 %.2f max %.2f" % (life.mean(), *np.percentile(life,[10,50,90]), life.max()))
 st = (t0[act]-base)/100.0
