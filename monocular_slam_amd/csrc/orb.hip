@@ -170,7 +170,7 @@ void resize_k(const uint8_t* __restrict__ src, int spitch, long long sfstride,
     const int ndw = dma ? cpr * 4 : ((sx_hi - sxa) >> 2) + 1;
     const bool use_lds = ndw * nrows < RS_LDS_DW && nrows <= RS_HROWS && ndw <= 128; // true for pyramid scales up to ~1.6
     const uint8_t* sb = src + b * sfstride;
-    const int tx = tid & 63, ty = tid >> 6;
+    const int tx = tid & 63, ty = __builtin_amdgcn_readfirstlane(tid >> 6);   // (the wavefront number as a scalar: row-table entries by scalar loads, row offsets on the scalar unit)
     const int x4 = x0 + tx * 4;
     uint8_t* db = dst + b * dfstride;
     if (dma && cpr <= RS_CPR && nrows <= RS_HROWS) {
