@@ -389,6 +389,66 @@ def test_ba_lm_converges_and_fixed_pose_stays(oracle):
     assert np.abs(np.linalg.norm(r["poses"][:, 3:], axis=1) - 1).max() < 1e-14
 
 
+def test_ba_robust_cost_and_minimum_against_scipy(oracle):
+    """Independent statement of the BA objective (numpy: e = obs - pi(R X + t), chi2 = info |e|^2, g2o's Huber rho) and an
+    independent minimiser (scipy.optimize.least_squares with loss='huber', whose rho is the same function): the oracle's
+    robust chi2 equals the numpy value, and where the oracle's LM stops scipy finds nothing better."""
+    from scipy.optimize import least_squares
+    from scipy.spatial.transform import Rotation
+    pr = synth.ba_problem(4, 60, 77)
+    delta = pr["huber_delta"]
+    dsqr = float(np.float32(delta * delta))   # g2o keeps delta^2 as a float (robust_kernel_impl.cpp:78-91)
+    ep, el, obs, info = pr["edge_pose"], pr["edge_point"], pr["obs"], pr["info"]
+    fx, fy, cx, cy = (pr["intr"][ep, k] for k in range(4))           # intrinsics per pose: (fx, fy, cx, cy)
+
+    def residuals_px(poses, points):
+        R = Rotation.from_quat(poses[:, 3:7]).as_matrix()          # (x, y, z, w)
+        Xc = np.einsum("eij,ej->ei", R[ep], points[el]) + poses[ep, :3]
+        proj = np.stack([fx * Xc[:, 0] / Xc[:, 2] + cx, fy * Xc[:, 1] / Xc[:, 2] + cy], axis=1)
+        return obs - proj
+
+    def robust(poses, points):
+        e = residuals_px(poses, points)
+        chi2 = info * (e ** 2).sum(axis=1)
+        return np.where(chi2 <= dsqr, chi2, 2 * np.sqrt(chi2) * delta - dsqr).sum()
+
+    s0 = oracle.ba_build(pr)
+    np.testing.assert_allclose(s0["err"], residuals_px(pr["poses"], pr["points"]), rtol=0, atol=1e-9)
+    np.testing.assert_allclose(s0["robust_chi2"], robust(pr["poses"], pr["points"]), rtol=1e-12)
+    r = oracle.ba_optimize(pr, 40)
+    c_lm = robust(r["poses"], r["points"])
+    np.testing.assert_allclose(r["chi2"][-1], c_lm, rtol=1e-10)
+
+    # scipy from the oracle's end state: free poses as (rotation vector increment, translation), points
+    free = [j for j in range(pr["n_poses"]) if not pr["pose_fixed"][j]]
+    R_end = Rotation.from_quat(r["poses"][:, 3:7])
+
+    def unpack(x):
+        poses = r["poses"].copy()
+        for k, j in enumerate(free):
+            dR = Rotation.from_rotvec(x[6 * k:6 * k + 3])
+            poses[j, 3:7] = (dR * R_end[j]).as_quat()
+            poses[j, :3] = r["poses"][j, :3] + x[6 * k + 3:6 * k + 6]
+        pts = r["points"] + x[6 * len(free):].reshape(-1, 3)
+        return poses, pts
+
+    # least_squares' Huber acts per scalar residual; g2o's acts on the edge's chi2 (two residuals together): compare at an
+    # edge-wise statement instead -- minimise the exact edge-wise robust cost through its square root as a residual vector
+    def fun_edge(x):
+        poses, pts = unpack(x)
+        e = residuals_px(poses, pts)
+        chi2 = info * (e ** 2).sum(axis=1)
+        rho = np.where(chi2 <= dsqr, chi2, 2 * np.sqrt(chi2) * delta - dsqr)
+        return np.sqrt(rho)
+
+    x0 = np.zeros(6 * len(free) + 3 * pr["n_points"])
+    assert abs((fun_edge(x0) ** 2).sum() - c_lm) <= 1e-9 * c_lm
+    sol = least_squares(fun_edge, x0, method="trf", xtol=1e-12, ftol=1e-12, gtol=1e-12, max_nfev=200)
+    c_sp = (sol.fun ** 2).sum()
+    # the LM of the reference stops on its own rule (relative decrease < 1e-3 three times): scipy may go on a little, not far
+    assert c_sp <= c_lm * (1 + 1e-12) and c_sp >= 0.98 * c_lm, (c_sp, c_lm)
+
+
 # ------------------------------------------------------------------ golden fixtures
 def test_oracle_reproduces_golden_fixtures(oracle):
     g = np.load(os.path.join(GOLD, "orb_320x240_seed4242.npz"))
