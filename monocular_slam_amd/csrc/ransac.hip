@@ -1103,9 +1103,10 @@ __device__ __forceinline__ bool pnp_has_dist(const double* k)
 }
 
 // ---- no-distortion scoring with a single-precision first tier -------------------------------------------------------
-// The division-free test above costs 18 double-precision instructions per (hypothesis, point); double precision occupies the
-// whole vector ALU (4 cycles per wave instruction, nothing else issues beside it), whereas v_fma/add/mul_f32 issue at twice
-// that rate and share the SIMD with the integer work of the extract kernels on the other streams (tools/ubench, profiles/r03_*).
+// The division-free test above costs 18 double-precision instructions per (hypothesis, point); a double-precision instruction
+// takes a SIMD's issue slot alone (4 cycles per wave instruction), whereas plain v_fma/add/mul_f32 issue at twice that rate when
+// two wavefronts of the SIMD have one ready (tools/ubench, profiles/r03_valu_rate_*.txt).  Alone on the chip this kernel scores
+// 15 % faster than the double test; beside the extract kernels of other streams the pairing is lost and nothing changes.
 // So the sign of  e = A^2 + B^2 - pz^2  is first formed in f32 from f32-rounded copies of the same inputs, together with a
 // rigorous bound m on |e32 - e*| (e* = the value in exact arithmetic on the double inputs):
 //   * a dot product fma(r0, X, fma(r1, Y, fma(r2, Z, r3))) of rounded inputs is within 5.01 u S of the exact one,
@@ -1150,9 +1151,9 @@ __device__ __noinline__ unsigned long long pnp_slot_f64(const PnpArgs& a, const 
     return in;
 }
 
-struct PnpModel32 { float r[12]; float rho_x, tau_x, rho_z, tau_z, tn; };
+struct PnpModel32 { float r[12]; float rho_x, tau_x, rho_z, tau_z, tn; };   // rows 0/1 scaled (threshold units), row 2, bounds
 constexpr int PNP32_PT = 8;       // points per lane of the f32 kernel
-constexpr int PNP_WQCAP = 1024;   // undecided pairs a wavefront can queue per pass over its points (a few dozen are, at the bench sizes)   // rows 0/1 scaled (threshold units), row 2, bounds
+constexpr int PNP_WQCAP = 1024;   // undecided pairs a wavefront can queue per pass over its points (a few dozen are, at the bench sizes)
 
 __device__ __forceinline__ void pnp_score_body_f32(const PnpArgs& a, int b, int h0, int nh, int tid, int lane, const double (*s_Rt)[12],
                                                    const double (*s_Rs)[8], const double* s_tn, const PnpModel32* s_m32, const int* s_valid, int* s_cnt, uint32_t* wq)

@@ -133,6 +133,22 @@ def test_noise_frame_with_far_more_candidates_than_select_keeps_in_registers(ctx
     _same_keypoints(kg, dg, ko, do)
 
 
+def test_tiles_where_more_than_half_the_pixels_survive_the_high_speed_test(ctx, oracle):
+    """fast_nms_k appends the corners of a tile to the upper half of its survivor list; a tile with more survivors than half the
+    list holds walks the survivor list again instead.  A one-pixel checkerboard passes the four-point test at every pixel (the
+    pixels 3 rows / columns away have the opposite colour) without being a corner; blobs and rectangles on top give real corners."""
+    img = synth.textured_frame(960, 540, 31).copy()
+    yy, xx = np.mgrid[0:540, 0:960]
+    board = (((xx + yy) & 1) * 200 + 20).astype(np.uint8)
+    img[100:400, 150:700] = board[100:400, 150:700]          # several whole 128 x 64 tiles of level 0 and of the next levels
+    img[180:260, 300:420] = synth.textured_frame(960, 540, 32)[180:260, 300:420]   # an island of texture inside the board
+    p = api.default_orb_params(1500)
+    kg, dg = ctx.orb_extract(img, p)
+    ko, do = oracle.orb_extract(img, _oracle_params(oracle, p), cap=8192)
+    assert len(ko) >= 1000
+    _same_keypoints(kg, dg, ko, do)
+
+
 def test_batched_device_extract(ctx, oracle):
     B, w, h, cap = 4, 640, 480, 1024
     frames = np.stack([synth.textured_frame(w, h, 100 + i) for i in range(B)])
