@@ -137,7 +137,7 @@ def main():
     ap.add_argument("--seq-len", type=int, default=48, help="consecutive frames per stream per step (a step = batch x seq-len frames; 48: the driver's --steps 20 times more than a second)")
     ap.add_argument("--no-ba", action="store_true", help="skip the BA build leg (roofline_ba: BASELINE configs[3], the path's HBM-bound kernel)")
     ap.add_argument("--sub-batches", type=int, default=2, help="the batch is enqueued as this many sub-batches on separate HIP streams")
-    ap.add_argument("--cpu-frames", type=int, default=24, help="frames of the cpu_baseline sample (0 = skip)")
+    ap.add_argument("--cpu-frames", type=int, default=64, help="frames of the cpu_baseline sample (0 = skip; 64 frames = about 12 s of one host core)")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip the event-instrumented passes (roofline block)")
     ap.add_argument("--no-ingest", action="store_true", help="skip the separately timed H2D-inclusive leg")
     ap.add_argument("--no-parity", action="store_true", help="skip the oracle check of the timed configuration's outputs")
