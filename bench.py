@@ -399,6 +399,26 @@ def main():
         read(kern_x)
         tbs[0].comm = saved_comm
 
+    # ---- separately timed leg: the same steps with the library's default PnP scoring (single-precision first tier of the inlier
+    # test, identical counts).  The headline above keeps the test in double precision; this is what a caller gets by default.
+    f32_leg = None
+    if world == 1 and os.environ.get("MSLAM_PNP_F32") == "0" and not os.environ.get("BENCH_NO_F32_LEG"):
+        os.environ["MSLAM_PNP_F32"] = "1"   # read by the library at every PnP call
+        n_f32 = max(2, min(args.steps, 8))
+        step(); barrier()
+        tq = time.perf_counter()
+        for _ in range(n_f32):
+            step()
+        barrier()
+        dq = time.perf_counter() - tq
+        res = [tb.results() for tb in tbs]
+        same = all(bool((r["status"] == 0).all() and (r["ninl"] > PNP_P // 2).all()) for r in res)
+        f32_leg = {"value": B * T * n_f32 / dq, "unit": "frames/s", "steps": n_f32, "valid_outputs": same,
+                   "note": "MSLAM_PNP_F32=1 (library default): pnp_score32_k decides the PnP inlier test in packed single precision under a rigorous "
+                           "error bound and hands the undecided pairs to the double-precision test; counts identical (tests/test_ransac_gpu.py)"}
+        del res
+        os.environ["MSLAM_PNP_F32"] = "0"
+
     # ---- separately timed leg: the same steps with every frame set uploaded from pinned host memory on a copy stream
     # (double-buffered against the previous step's kernels).  PCIe-inclusive; reported beside `value`, never as it.
     ingest = None
@@ -454,6 +474,8 @@ def main():
             out["collective"] = collective
         if ingest is not None:
             out["ingest_inclusive"] = ingest
+        if f32_leg is not None:
+            out["with_pnp_f32_tier"] = f32_leg
         if kern:
             out.update(roofline_blocks(kern, kern_x, NPROF, SB, NS, value, world))
         if not args.no_ba and world == 1:

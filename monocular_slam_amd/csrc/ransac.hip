@@ -1103,10 +1103,12 @@ __device__ __forceinline__ bool pnp_has_dist(const double* k)
 }
 
 // ---- no-distortion scoring with a single-precision first tier -------------------------------------------------------
-// The division-free test above costs 18 double-precision instructions per (hypothesis, point); a double-precision instruction
-// takes a SIMD's issue slot alone (4 cycles per wave instruction), whereas plain v_fma/add/mul_f32 issue at twice that rate when
-// two wavefronts of the SIMD have one ready (tools/ubench, profiles/r03_valu_rate_*.txt).  Alone on the chip this kernel scores
-// 15 % faster than the double test; beside the extract kernels of other streams the pairing is lost and nothing changes.
+// The division-free test above costs 18 double-precision instructions per (hypothesis, point), each of which takes a SIMD's issue
+// slot alone (4 cycles per wave instruction).  A packed single-precision instruction (v_pk_fma_f32) takes the same slot but
+// carries two points: 8 packed instructions + 2 compares per pair here.  (Plain v_fma_f32 issues at twice the rate when two
+// wavefronts of the SIMD have one ready -- tools/ubench, profiles/r03_valu_rate_*.txt -- and a first form of this kernel was
+// built on that: 15 % faster alone, no gain beside the extract kernels of other streams, whose wavefronts take the pairing away.
+// The packed form does not depend on it: 15 % faster alone, +1.8 % frames/s in the bench's schedule.)
 // So the sign of  e = A^2 + B^2 - pz^2  is first formed in f32 from f32-rounded copies of the same inputs, together with a
 // rigorous bound m on |e32 - e*| (e* = the value in exact arithmetic on the double inputs):
 //   * a dot product fma(r0, X, fma(r1, Y, fma(r2, Z, r3))) of rounded inputs is within 5.01 u S of the exact one,
@@ -1114,8 +1116,11 @@ __device__ __forceinline__ bool pnp_has_dist(const double* k)
 //   * A32 = fma(-oc32, pz32, px32) is within 7.1 u (Sx + |oc| Sz) of A*;  E = 8.5 u (Sxb + (ocm + 1) Szb) bounds the error of
 //     A32, B32 and pz32 alike, with Sxb = rho_x nu + tau_x >= Sx, Sy and Szb = rho_z nu + tau_z >= Sz formed once per
 //     (hypothesis, lane) from per-hypothesis row norms and the lane's largest |X|+|Y|+|Z| and |oc| (all rounded up);
-//   * |e32 - e*| <= 2 E s + 3 E^2 + 3.01 u s^2  with  s = |A32| + |B32| + |pz32|.
-// m = s (2.02 E + 32 u s) + 3.1 E^2 leaves 1.7e-6 s^2 >= 1.7e-6 pz^2 beyond that, so a pair decided here (|e32| > m, and
+//   * |e32 - e*| <= 2 E s + 3 E^2 + 3.01 u s^2  with  s = |A32| + |B32| + |pz32|;  with  2 E s <= E (s^2 / sigma + sigma)  for any
+//     sigma > 0 and  s^2 <= 3 T,  T = A32^2 + B32^2 + pz32^2 = e32 + 2 pz32^2 (one fma, within 6 u T),  this is
+//     <= E sigma + 3 E^2 + (3 E / sigma + 9.1 u) T:  a shell that is ONE fma of T.
+// m = c0 + c1 t32,  c0 = E sigma + 3.1 E^2,  c1 = 3.05 E / sigma + 27 u  (sigma ~ s on the threshold circle at the scene's depth) leaves
+// 1e-6 T >= 1e-6 pz^2 beyond that, so a pair decided here (|e32| > m, and
 // |pz32| >= 1.01 zg + E, the double test's guard against a vanishing depth) lies outside the double test's own 1e-6 shell with
 // the same sign: the count is the one the double test, and therefore the exact rule, gives.  Everything else -- about 0.15 % of
 // the pairs at the bench sizes, one (hypothesis, point slot) in ten holds such a lane -- is appended to the wavefront's own queue in
@@ -1151,12 +1156,16 @@ __device__ __noinline__ unsigned long long pnp_slot_f64(const PnpArgs& a, const 
     return in;
 }
 
-struct PnpModel32 { float r[12]; float rho_x, tau_x, rho_z, tau_z, tn; };   // rows 0/1 scaled (threshold units), row 2, bounds
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f32x2 pk_bc(float x) { return (f32x2){ x, x }; }
+struct alignas(16) PnpModel32 { float r[12]; float c0, c1, zg, pad; };   // rows 0/1 scaled (threshold units), row 2; the shell m = c0 + c1 t and the depth guard (per pass over the points)
+struct PnpBound32 { float e_ocnu, e_oc, e_nu, e_1, s_nu, s_1, tn; };             // per-hypothesis factors of the error bound
 constexpr int PNP32_PT = 8;       // points per lane of the f32 kernel
 constexpr int PNP_WQCAP = 1024;   // undecided pairs a wavefront can queue per pass over its points (a few dozen are, at the bench sizes)
 
 __device__ __forceinline__ void pnp_score_body_f32(const PnpArgs& a, int b, int h0, int nh, int tid, int lane, const double (*s_Rt)[12],
-                                                   const double (*s_Rs)[8], const double* s_tn, const PnpModel32* s_m32, const int* s_valid, int* s_cnt, uint32_t* wq)
+                                                   const double (*s_Rs)[8], const double* s_tn, PnpModel32* s_m32, const PnpBound32* s_b32, float* s_red, const int* s_valid, int* s_cnt, uint32_t* wq)
 {
     const int P = a.P[b];
     const double* K = a.K + b * 9;
@@ -1169,9 +1178,9 @@ __device__ __forceinline__ void pnp_score_body_f32(const PnpArgs& a, int b, int 
     const double sf = (fabs(fx) > fabs(fy) ? fabs(fx) : fabs(fy)) * inv_thr;
     const float UP = 1.0f + 0x1p-20f;                       // a rounded-to-nearest float times UP is >= the value it was rounded from
     const float sf32 = (float)sf * UP;
-    constexpr float CE = 8.5f * 0x1p-24f, C2 = 32.5f * 0x1p-24f;
+    constexpr float C1 = 27.0f * 0x1p-24f;
     for (int c0 = 0; c0 < P; c0 += SCORE_THREADS * PNP32_PT) {
-        float X[PNP32_PT], Y[PNP32_PT], Z[PNP32_PT], ocx[PNP32_PT], ocy[PNP32_PT];
+        f32x2 X2[PNP32_PT / 2], Y2[PNP32_PT / 2], Z2[PNP32_PT / 2], nox[PNP32_PT / 2], noy[PNP32_PT / 2];   // points 2 jj, 2 jj + 1; (oc negated)
         unsigned long long livem[PNP32_PT];
         double nrm = 0.0;
         float ocm = 0.f;
@@ -1187,57 +1196,79 @@ __device__ __forceinline__ void pnp_score_body_f32(const PnpArgs& a, int b, int 
             // A lane without a point gets one that every hypothesis rejects with certainty (an observation 1e15 thresholds away:
             // e ~ 1e30 pz^2 is far outside the shell, never an inlier), so the hot loop needs no liveness mask; if pz vanishes the
             // slot takes the double test, which masks by liveness.
-            X[j] = live ? (float)Xd : 0.f; Y[j] = live ? (float)Yd : 0.f; Z[j] = live ? (float)Zd : 0.f;
-            ocx[j] = live ? (float)ocxd : 1e15f; ocy[j] = live ? (float)ocyd : 1e15f;
+            const float xf = live ? (float)Xd : 0.f, yf = live ? (float)Yd : 0.f, zf = live ? (float)Zd : 0.f;
+            const float oxf = live ? (float)ocxd : 1e15f, oyf = live ? (float)ocyd : 1e15f;
+            if (j & 1) { X2[j / 2].y = xf; Y2[j / 2].y = yf; Z2[j / 2].y = zf; nox[j / 2].y = -oxf; noy[j / 2].y = -oyf; }
+            else { X2[j / 2].x = xf; Y2[j / 2].x = yf; Z2[j / 2].x = zf; nox[j / 2].x = -oxf; noy[j / 2].x = -oyf; }
             if (live) {
                 nrm = fmax(nrm, fabs(Xd) + fabs(Yd) + fabs(Zd));   // the double test's own quantity (its zg uses it)
-                ocm = fmaxf(ocm, fmaxf(fabsf(ocx[j]), fabsf(ocy[j])));
+                ocm = fmaxf(ocm, fmaxf(fabsf(oxf), fabsf(oyf)));
             }
         }
-        const float nu = (float)nrm * UP;
-        ocm = ocm * UP + 1.0f;
-        // the f32 tier needs a sane dynamic range: otherwise every slot takes the double test (an infinite depth guard does that)
-        const bool tier_ok = thr_ok && sf32 < 1e15f && __builtin_amdgcn_ballot_w64(!(nu < 1e15f && ocm < 1e15f)) == 0;   // wave-uniform
-        const float guard_scale = tier_ok ? 1.01e-7f * sf32 : __builtin_inff();
+        // The shell m = c0 + c1 t and the depth guard are formed once per (hypothesis, pass over the points) by the first 32 lanes, from
+        // the workgroup's largest |X|_1 and |oc| (a bound for every lane; per-lane values would cost a dozen instructions per
+        // (hypothesis, lane) for a few per cent of tightness) and the per-hypothesis factors of the prologue
+        float nu = (float)nrm * UP;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { nu = fmaxf(nu, __shfl_xor(nu, o)); ocm = fmaxf(ocm, __shfl_xor(ocm, o)); }
+        __syncthreads();   // the previous pass is done with s_red and the shell constants
+        if (lane == 0) { s_red[2 * (tid >> 6)] = nu; s_red[2 * (tid >> 6) + 1] = ocm; }
+        __syncthreads();
+        if (tid < PNP_HPB) {
+            float nuw = 0.f, ocw = 0.f;
+#pragma unroll
+            for (int w = 0; w < SCORE_THREADS / 64; w++) { nuw = fmaxf(nuw, s_red[2 * w]); ocw = fmaxf(ocw, s_red[2 * w + 1]); }
+            ocw = ocw * UP + 1.0f;
+            const bool tier_ok = thr_ok && sf32 < 1e15f && nuw < 1e15f && ocw < 1e15f;   // a sane dynamic range, else every pair goes to the second tier
+            const PnpBound32 Bq = s_b32[tid];
+            const float E = fmaf(Bq.e_ocnu, ocw * nuw * UP, fmaf(Bq.e_oc, ocw, fmaf(Bq.e_nu, nuw, Bq.e_1)));   // CE (Sxb + ocm Szb)
+            const float sigma = fmaf(Bq.s_nu, nuw, Bq.s_1);     // about s on the threshold circle at the scene's depth (any positive value is valid)
+            const float rs = __builtin_amdgcn_rcpf(sigma) * UP;  // >= 1 / sigma (v_rcp_f32 is within one ulp)
+            s_m32[tid].c0 = E * fmaf(3.1f, E, sigma);
+            s_m32[tid].c1 = fmaf(3.05f * E, rs, C1);
+            s_m32[tid].zg = tier_ok ? fmaf(1.01e-7f * sf32, nuw + Bq.tn, E) + 1e-30f : __builtin_inff();
+        }
+        __syncthreads();
         // the hypotheses to score as a mask in a scalar register (no LDS round trip per hypothesis to learn that it has a pose)
         unsigned vmask = (unsigned)__builtin_amdgcn_ballot_w64(lane < nh && s_valid[lane & (PNP_HPB - 1)] != 0);
         while (vmask) {
             const int q = __builtin_ctz(vmask);
             vmask &= vmask - 1;
-            const PnpModel32& M = s_m32[q];
-            float r[12];
-#pragma unroll
-            for (int e = 0; e < 12; e++) r[e] = M.r[e];
-            // error bound of A32, B32, pz32 for this (hypothesis, lane), and the depth guard
-            const float Sxb = fmaf(M.rho_x, nu, M.tau_x), Szb = fmaf(M.rho_z, nu, M.tau_z);
-            const float E = CE * fmaf(ocm, Szb, Sxb);
-            const float twoE = 2.02f * E, E2 = 3.1f * E * E;
-            const float zg32 = fmaf(guard_scale, nu + M.tn, E) + 1e-30f;
+            const float4* mp = reinterpret_cast<const float4*>(&s_m32[q]);   // 64 bytes: four 16-byte LDS reads from one address
+            const float4 m0 = mp[0], m1 = mp[1], m2 = mp[2], m3 = mp[3];
+            const float r[12] = { m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w, m2.x, m2.y, m2.z, m2.w };
+            const float c0m = m3.x, c1m = m3.y, zg32 = m3.z;
             int cnt = 0;
             unsigned long long um[PNP32_PT], inm[PNP32_PT], any = 0;
             float pzmin = __builtin_inff();
 #pragma unroll
-            for (int j = 0; j < PNP32_PT; j++) {
-                const float pz = fmaf(r[8], X[j], fmaf(r[9], Y[j], fmaf(r[10], Z[j], r[11])));
-                const float px = fmaf(r[0], X[j], fmaf(r[1], Y[j], fmaf(r[2], Z[j], r[3])));
-                const float py = fmaf(r[4], X[j], fmaf(r[5], Y[j], fmaf(r[6], Z[j], r[7])));
-                const float A = fmaf(-ocx[j], pz, px), Bv = fmaf(-ocy[j], pz, py);
-                const float e = fmaf(A, A, fmaf(Bv, Bv, -(pz * pz)));
-                const float s = fabsf(A) + fabsf(Bv) + fabsf(pz);
-                const float m = fmaf(s, fmaf(C2, s, twoE), E2);
+            for (int jj = 0; jj < PNP32_PT / 2; jj++) {
+                // two points per instruction (v_pk_fma_f32, the model coefficient broadcast by op_sel): a packed instruction takes the
+                // issue slot alone like a double-precision one, but carries two pairs
+                const f32x2 pz = pk_fma(pk_bc(r[8]), X2[jj], pk_fma(pk_bc(r[9]), Y2[jj], pk_fma(pk_bc(r[10]), Z2[jj], pk_bc(r[11]))));
+                const f32x2 px = pk_fma(pk_bc(r[0]), X2[jj], pk_fma(pk_bc(r[1]), Y2[jj], pk_fma(pk_bc(r[2]), Z2[jj], pk_bc(r[3]))));
+                const f32x2 py = pk_fma(pk_bc(r[4]), X2[jj], pk_fma(pk_bc(r[5]), Y2[jj], pk_fma(pk_bc(r[6]), Z2[jj], pk_bc(r[7]))));
+                const f32x2 A = pk_fma(nox[jj], pz, px), Bv = pk_fma(noy[jj], pz, py);
+                const f32x2 p2 = pz * pz;
+                const f32x2 e = pk_fma(A, A, pk_fma(Bv, Bv, -p2));
+                const f32x2 t = pk_fma(pk_bc(2.0f), p2, e);                 // A^2 + B^2 + pz^2
+                const f32x2 m = pk_fma(pk_bc(c1m), t, pk_bc(c0m));
                 // scalar-unit work per pair kept to a popcount, an add and an or: the scalar unit serves all four SIMDs of the CU
-                um[j] = __builtin_amdgcn_ballot_w64(!(fabsf(e) > m));
-                inm[j] = __builtin_amdgcn_ballot_w64(e < -m);
-                cnt += __popcll(inm[j]);
-                any |= um[j];
-                pzmin = fminf(pzmin, fabsf(pz));   // the depth guard is checked once per hypothesis (v_min3 folds two points per instruction)
+                um[2 * jj] = __builtin_amdgcn_ballot_w64(!(fabsf(e.x) > m.x));
+                um[2 * jj + 1] = __builtin_amdgcn_ballot_w64(!(fabsf(e.y) > m.y));
+                inm[2 * jj] = __builtin_amdgcn_ballot_w64(e.x < -m.x);
+                inm[2 * jj + 1] = __builtin_amdgcn_ballot_w64(e.y < -m.y);
+                cnt += __popcll(inm[2 * jj]) + __popcll(inm[2 * jj + 1]);
+                any |= um[2 * jj] | um[2 * jj + 1];
+                pzmin = fminf(pzmin, fminf(fabsf(pz.x), fabsf(pz.y)));   // the depth guard is checked once per hypothesis (one v_min3 per two points)
             }
             {   // depth guard: rare (pz is metres in front of the camera), so it is checked once per hypothesis on the lane's smallest
                 // |pz| and the slots it concerns are found again only then (a lane without a point has pz = t_z, which may be small)
                 if (__builtin_amdgcn_ballot_w64(!(pzmin >= zg32))) {
 #pragma unroll
                     for (int j = 0; j < PNP32_PT; j++) {
-                        const float pz = fmaf(r[8], X[j], fmaf(r[9], Y[j], fmaf(r[10], Z[j], r[11])));
+                        const float xj = (j & 1) ? X2[j / 2].y : X2[j / 2].x, yj = (j & 1) ? Y2[j / 2].y : Y2[j / 2].x, zj = (j & 1) ? Z2[j / 2].y : Z2[j / 2].x;
+                        const float pz = fmaf(r[8], xj, fmaf(r[9], yj, fmaf(r[10], zj, r[11])));
                         const unsigned long long g = __builtin_amdgcn_ballot_w64(!(fabsf(pz) >= zg32)) & livem[j];
                         um[j] |= g; any |= g;
                     }
@@ -1350,6 +1381,8 @@ void pnp_score32_k(PnpArgs a)
     __shared__ int s_cnt[PNP_HPB];
     __shared__ int s_valid[PNP_HPB];
     __shared__ PnpModel32 s_m32[PNP_HPB];
+    __shared__ PnpBound32 s_b32[PNP_HPB];
+    __shared__ float s_red[2 * SCORE_THREADS / 64];
     __shared__ uint32_t s_queue[SCORE_THREADS / 64][PNP_WQCAP];
     {
         const double* K = a.K + b * 9;
@@ -1374,15 +1407,22 @@ void pnp_score32_k(PnpArgs a)
 #pragma unroll
         for (int e = 8; e < 12; e++) M.r[e] = (float)s_Rt[tid][e];
         const double* R = s_Rs[tid];
-        M.rho_x = (float)fmax(fmax(fmax(fabs(R[0]), fabs(R[1])), fabs(R[2])), fmax(fmax(fabs(R[4]), fabs(R[5])), fabs(R[6]))) * UP;
-        M.tau_x = (float)fmax(fabs(R[3]), fabs(R[7])) * UP;
-        M.rho_z = (float)fmax(fmax(fabs(s_Rt[tid][8]), fabs(s_Rt[tid][9])), fabs(s_Rt[tid][10])) * UP;
-        M.tau_z = (float)fabs(s_Rt[tid][11]) * UP;
-        M.tn = (float)s_tn[tid] * UP;
+        const float rho_x = (float)fmax(fmax(fmax(fabs(R[0]), fabs(R[1])), fabs(R[2])), fmax(fmax(fabs(R[4]), fabs(R[5])), fabs(R[6]))) * UP;
+        const float tau_x = (float)fmax(fabs(R[3]), fabs(R[7])) * UP;
+        const float rho_z = (float)fmax(fmax(fabs(s_Rt[tid][8]), fabs(s_Rt[tid][9])), fabs(s_Rt[tid][10])) * UP;
+        const float tau_z = (float)fabs(s_Rt[tid][11]) * UP;
+        // E = CE (rho_x nu + tau_x + ocm (rho_z nu + tau_z)), sigma = 2.4 (rho_z nu / 2 + tau_z): the per-hypothesis factors (rounded up)
+        constexpr float CE = 8.5f * 0x1p-24f;
+        PnpBound32 Bq;
+        Bq.e_ocnu = CE * rho_z * UP; Bq.e_oc = CE * tau_z * UP; Bq.e_nu = CE * rho_x * UP; Bq.e_1 = CE * tau_x * UP;
+        Bq.s_nu = 1.2f * rho_z; Bq.s_1 = 2.4f * tau_z + 1e-30f;
+        Bq.tn = (float)s_tn[tid] * UP;
+        M.c0 = M.c1 = M.zg = M.pad = 0.f;
         s_m32[tid] = M;
+        s_b32[tid] = Bq;
     }
     __syncthreads();
-    pnp_score_body_f32(a, b, h0, nh, tid, lane, s_Rt, s_Rs, s_tn, s_m32, s_valid, s_cnt, s_queue[tid >> 6]);
+    pnp_score_body_f32(a, b, h0, nh, tid, lane, s_Rt, s_Rs, s_tn, s_m32, s_b32, s_red, s_valid, s_cnt, s_queue[tid >> 6]);
     __syncthreads();
     if (tid < nh) a.counts[(size_t)b * a.H + h0 + tid] = s_valid[tid] ? s_cnt[tid] : 0;
 }
