@@ -320,7 +320,10 @@ int mslam_match_knn2_batch_dev(mslam_ctx* ctx, const uint8_t* q, const int32_t* 
     if (use_mfma && cap < MF_SCALE) {   // (train indices live below MF_SCALE in the keys; larger capacities take the VALU form)
         const int tiles_cap = (cap + 31) / 32;
         static int stamp_calls = 0;
-        static unsigned long long* stamps = [] { unsigned long long* p = nullptr; if (getenv("MSLAM_MATCH_DEBUG") && hipMalloc(&p, 8 * 4 * 65536) == hipSuccess) (void)hipMemset(p, 0, 8 * 4 * 65536); return p; }();
+        // (development hook: the buffer lives on the device that was current at the first call and is used by contexts of that device only)
+        static int stamps_device = -1;
+        static unsigned long long* stamps_buf = [] { unsigned long long* p = nullptr; if (getenv("MSLAM_MATCH_DEBUG") && hipGetDevice(&stamps_device) == hipSuccess && hipMalloc(&p, 8 * 4 * 65536) == hipSuccess) (void)hipMemset(p, 0, 8 * 4 * 65536); return p; }();
+        unsigned long long* stamps = stamps_device == ctx->device ? stamps_buf : nullptr;
         static const int nsplit = [] { const char* e = getenv("MSLAM_MATCH_SPLIT"); const int v = e ? atoi(e) : 4; return v < 1 ? 1 : (v > 16 ? 16 : v); }();
         const size_t e_bytes = align_up((size_t)B * tiles_cap * 8192, 256), p_bytes = align_up(sizeof(uint2) * (size_t)B * nsplit * cap, 256);
         MSLAM_TRY(ctx_scratch(ctx, 2 * e_bytes + p_bytes, &scr));
