@@ -638,18 +638,30 @@ void fast_nms_k(OrbDev od)
             const uint32_t* rowp = s_pix + (sy + 3) * (FP_PITCH / 4) + g; // rows/columns exist in LDS for every lane
             const uint32_t Lw = rowp[0], Cw = rowp[1], Rw = rowp[2];
             const uint32_t Tw = rowp[1 - 3 * (FP_PITCH / 4)], Bw = rowp[1 + 3 * (FP_PITCH / 4)];
-            const uint32_t P4 = __builtin_amdgcn_alignbyte(Rw, Cw, 3);   // pixels at x + 3
-            const uint32_t P12 = __builtin_amdgcn_alignbyte(Cw, Lw, 1);  // pixels at x - 3
+            // two pixels per packed 16-bit instruction: E = pixels (0, 2), O = pixels (1, 3) of the lane's four, each ring pixel
+            // pair picked out of the dwords by one v_perm_b32 / v_and_b32 (selector 0x0c = constant zero byte)
+            typedef unsigned short u2v __attribute__((ext_vector_type(2)));
+#define U2(x) __builtin_bit_cast(u2v, (uint32_t)(x))
+#define UMIN(a, b) __builtin_elementwise_min(a, b)
+#define UMAX(a, b) __builtin_elementwise_max(a, b)
+            const u2v cE = U2(Cw & 0x00FF00FFu), cO = U2(__builtin_amdgcn_perm(0u, Cw, 0x0c030c01u));
+            const u2v tE = U2(Tw & 0x00FF00FFu), tO = U2(__builtin_amdgcn_perm(0u, Tw, 0x0c030c01u));
+            const u2v bE = U2(Bw & 0x00FF00FFu), bO = U2(__builtin_amdgcn_perm(0u, Bw, 0x0c030c01u));
+            // x + 3: pixel k is byte k + 3 of (Cw, Rw); x - 3: pixel k is byte k + 1 of (Lw, Cw)
+            const u2v rE = U2(__builtin_amdgcn_perm(Rw, Cw, 0x0c050c03u)), rO = U2(Rw & 0x00FF00FFu);
+            const u2v lE = U2(__builtin_amdgcn_perm(0u, Lw, 0x0c030c01u)), lO = U2(__builtin_amdgcn_perm(Cw, Lw, 0x0c040c02u));
+            // brighter: min(max(p0, p8), max(p4, p12)) - v > thr; darker: v - max(min(p0, p8), min(p4, p12)) > thr
+            const s2v mE = __builtin_elementwise_max(__builtin_bit_cast(s2v, UMIN(UMAX(tE, bE), UMAX(rE, lE)) - cE),
+                                                      __builtin_bit_cast(s2v, cE - UMAX(UMIN(tE, bE), UMIN(rE, lE))));
+            const s2v mO = __builtin_elementwise_max(__builtin_bit_cast(s2v, UMIN(UMAX(tO, bO), UMAX(rO, lO)) - cO),
+                                                      __builtin_bit_cast(s2v, cO - UMAX(UMIN(tO, bO), UMIN(rO, lO))));
+#undef U2
+#undef UMIN
+#undef UMAX
+            const short m4[4] = { mE.x, mO.x, mE.y, mO.y };
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                const uint32_t v = byte_of(Cw, k);
-                const uint32_t hi = v + (uint32_t)thr;
-                const int lo = (int)v - thr;
-                const uint32_t p0 = byte_of(Bw, k), p8 = byte_of(Tw, k), p4 = byte_of(P4, k), p12 = byte_of(P12, k);
-                // (p0 > hi | p8 > hi) & (p4 > hi | p12 > hi)  ==  min(max(p0, p8), max(p4, p12)) > hi, and mirrored
-                const unsigned long long brig = __builtin_amdgcn_ballot_w64(min(max(p0, p8), max(p4, p12)) > hi);
-                const unsigned long long dark = __builtin_amdgcn_ballot_w64(max(min((int)p0, (int)p8), min((int)p4, (int)p12)) < lo);
-                bal[m][k] = (brig | dark) & rowok & colok[k];
+                bal[m][k] = __builtin_amdgcn_ballot_w64((int)m4[k] > thr) & rowok & colok[k];
                 tot += __popcll(bal[m][k]);
             }
         }
@@ -691,6 +703,7 @@ void fast_nms_k(OrbDev od)
             // packed differences D[k] = (v - p[k], v - p[k + 8]).  The segment test needs no masks of its own: an arc of 9 ring
             // pixels all darker than v - thr exists iff max over arcs of min(d) > thr, all brighter iff min over arcs of
             // max(d) < -thr -- the two quantities the exact score is made of.  So: score + 1 > thr <=> corner.
+            // (ds_read_u8_d16_hi would drop the packing instructions, but with SRAM ECC a d16 load clears the other half.)
             const s2v V2 = __builtin_bit_cast(s2v, v | (v << 16));
             s2v D[8];
 #pragma unroll
