@@ -210,6 +210,31 @@ int mslam_fmat_ransac8_batch_dev(mslam_ctx* ctx, const double* x1, const double*
                                  const mslam_fmat_params* params, double* F, uint8_t* status,
                                  int32_t* inlier_counts, int32_t* best_h, int32_t* n_inliers);
 
+/* ---- R8 as the reference's live path runs it: findFundamentalMat(CV_FM_RANSAC, 3.0, 0.85) (src/CameraPoseEstimator.cpp:563)
+ * OpenCV 2.4.13's estimator with 7-point minimal samples (CvFMEstimator::run7Point: the null space of the 7 x 9 system is two-
+ * dimensional, det(lambda f1 + (1 - lambda) f2) = 0 gives up to three matrices per sample, each scaled to F[8] = 1), every
+ * matrix scored by computeReprojError (metric 1 above), and cvFindFundamentalMat's choice of estimator by the number of pairs:
+ * runRANSAC for M >= 15 (record + adaptive iteration bound, tested once per sample), runLMeDS for 8 <= M < 15 (least median
+ * of the errors over cvRound(log(1 - confidence) / log(1 - 0.55^7)) samples, at least 3, at most H; inlier threshold
+ * sigma = 2.5 * 1.4826 * (1 + 5 / (M - 7)) * sqrt(median), at least 0.001; fewer than 7 inliers = failure), and the direct
+ * solution for M == 7 (first matrix of sample 0, every pair an inlier).  OpenCV is absent: restated from its published
+ * algorithm, parity unpinned; the null space comes from Gauss-Jordan elimination instead of an SVD and the cubic from a Newton
+ * iteration + deflation instead of acos / cos / cbrt (identical operation for operation in the CPU oracle), roots in
+ * cvSolveCubic's order.
+ * samples: H x 7 indices.  method: 0 = cvFindFundamentalMat's choice (above), 1 = runRANSAC, 2 = runLMeDS (M <= 32 only).
+ * params: metric must be 1; threshold / confidence as above (LMedS reads a confidence outside (0,1) as 0.99, like OpenCV);
+ * refit 0 = the winning matrix, 2 = CV_FM_8POINT on its inliers when there are at least 8 (the reference's second call, :585).
+ * inlier_counts (optional): H x 3, zero where a sample yields fewer matrices and for problems RANSAC does not run on.
+ * best_model = 3 * sample + root of the winner, -1 (and MSLAM_ERR_DEGENERATE from the host form) if there is none. */
+int mslam_fmat_ransac7(mslam_ctx* ctx, const double* x1, const double* x2, int M,
+                       const int32_t* samples, int H, const mslam_fmat_params* params, int method,
+                       double F[9], uint8_t* status, int32_t* inlier_counts, int* best_model,
+                       int* n_inliers);
+int mslam_fmat_ransac7_batch_dev(mslam_ctx* ctx, const double* x1, const double* x2, const int32_t* M,
+                                 int capM, const int32_t* samples, int H, int B,
+                                 const mslam_fmat_params* params, int method, double* F, uint8_t* status,
+                                 int32_t* inlier_counts, int32_t* best_model, int32_t* n_inliers);
+
 /* ---- R12: PnP RANSAC ------------------------------------------------------------------
  * Stands in for `solvePnPRansac(mapPoints, imagePoints, curK, distCoeff, rvec, tvec)`
  * + Rodrigues (src/CameraPoseEstimator.cpp:472-473).  OpenCV 2.4's implementation is

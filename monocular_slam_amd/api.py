@@ -388,6 +388,22 @@ def _ctx_methods():
             self._check(rc, "mslam_fmat_ransac8")
         return dict(rc=rc, F=F.reshape(3, 3), status=status, counts=counts, best_h=best.value, n_inliers=ninl.value)
 
+    def fmat_ransac7(self, x1, x2, samples, params: FmatParams, method: int = 0, want_counts: bool = True):
+        """R8 as the reference's live path runs it (findFundamentalMat(CV_FM_RANSAC), src/CameraPoseEstimator.cpp:563): 7-point
+        samples (H x 7), up to three matrices each; method 0 = OpenCV's choice by the number of pairs (RANSAC / LMedS / direct)."""
+        x1 = np.ascontiguousarray(x1, np.float64); x2 = np.ascontiguousarray(x2, np.float64)
+        samples = np.ascontiguousarray(samples, np.int32)
+        M, H = x1.shape[0], samples.shape[0]
+        assert samples.shape[1] == 7
+        F = np.zeros(9); status = np.zeros(M, np.uint8); counts = np.zeros(3 * H, np.int32) if want_counts else None
+        best, ninl = C.c_int(-1), C.c_int(0)
+        rc = lib().mslam_fmat_ransac7(self._h, _p(x1, f64p), _p(x2, f64p), M, _p(samples, i32p), H, C.byref(params), int(method),
+                                      _p(F, f64p), _p(status, u8p), _p(counts, i32p) if want_counts else None, C.byref(best), C.byref(ninl))
+        if rc not in (OK, ERR_DEGENERATE):
+            self._check(rc, "mslam_fmat_ransac7")
+        return dict(rc=rc, F=F.reshape(3, 3), status=status, counts=counts.reshape(H, 3) if want_counts else None,
+                    best_model=best.value, n_inliers=ninl.value)
+
     def pnp_ransac(self, X, x, K, dist, samples, params: PnpParams):
         """R12: PnP RANSAC (P3P hypotheses over an explicit H x 4 sample table)."""
         X = np.ascontiguousarray(X, np.float64); x = np.ascontiguousarray(x, np.float64)
@@ -458,6 +474,13 @@ def _ctx_methods():
                                                        vp(counts_ptr) if counts_ptr else None, vp(best_ptr), vp(ninl_ptr)),
                     "mslam_fmat_ransac8_batch_dev")
 
+    def fmat_ransac7_batch_dev(self, x1_ptr, x2_ptr, M_ptr, capM, samples_ptr, H, B, params, method, F_ptr, status_ptr,
+                               counts_ptr, best_ptr, ninl_ptr):
+        self._check(lib().mslam_fmat_ransac7_batch_dev(self._h, vp(x1_ptr), vp(x2_ptr), vp(M_ptr), capM, vp(samples_ptr), H, B,
+                                                       C.byref(params), int(method), vp(F_ptr), vp(status_ptr),
+                                                       vp(counts_ptr) if counts_ptr else None, vp(best_ptr), vp(ninl_ptr)),
+                    "mslam_fmat_ransac7_batch_dev")
+
     def pnp_ransac_batch_dev(self, X_ptr, x_ptr, P_ptr, capP, K_ptr, dist_ptr, samples_ptr, H, B, params, Rt_ptr,
                              rvec_ptr, tvec_ptr, inl_ptr, counts_ptr, best_ptr, ninl_ptr):
         def o(p):
@@ -478,7 +501,7 @@ def _ctx_methods():
         a.update(robust_chi2=ss.robust_chi2, n_free_poses=ss.n_free_poses, nnzb=ss.nnzb)
         return a
 
-    for f in (fmat_ransac8, pnp_ransac, triangulate, triangulate_batch, sample_tables_dev, sample_tables, gather_matches_dev,
+    for f in (fmat_ransac8, fmat_ransac7, fmat_ransac7_batch_dev, pnp_ransac, triangulate, triangulate_batch, sample_tables_dev, sample_tables, gather_matches_dev,
               fmat_ransac8_batch_dev, pnp_ransac_batch_dev, ba_build):
         setattr(Context, f.__name__, f)
 

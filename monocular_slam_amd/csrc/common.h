@@ -16,7 +16,7 @@ enum KernelId {
     K_GRAY = 0, K_RESIZE, K_FAST_NMS, K_SELECT, K_DESCRIBE, K_MATCH_PARTIAL, K_MATCH_FINALIZE,
     K_FMAT_PREPARE, K_FMAT_SOLVE, K_FMAT_SCORE, K_FMAT_FINALIZE, K_RANSAC_SELECT,
     K_PNP_PREPARE, K_PNP_SOLVE, K_PNP_SCORE, K_PNP_FINALIZE, K_TRIANGULATE,
-    K_BA_POINTS, K_BA_POSES, K_BA_FINAL, K_BA_SCHUR, K_BA_SCHUR_TILES, K_BA_SCHUR_FINAL, K_BA_BACKSUB, K_PYRAMID2, K_MATCH_EXPAND, K_MATCH_MFMA, K_PNP_SCORE32, K_COUNT
+    K_BA_POINTS, K_BA_POSES, K_BA_FINAL, K_BA_SCHUR, K_BA_SCHUR_TILES, K_BA_SCHUR_FINAL, K_BA_BACKSUB, K_PYRAMID2, K_MATCH_EXPAND, K_MATCH_MFMA, K_PNP_SCORE32, K_FMAT7_SOLVE, K_FMAT7_LMEDS, K_COUNT
 };
 extern const char* const kKernelNames[K_COUNT];
 

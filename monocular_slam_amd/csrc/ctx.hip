@@ -7,7 +7,7 @@ const char* const kKernelNames[K_COUNT] = {
     "bgr2gray_k", "resize_k", "fast_nms_k", "select_k", "describe_k", "hamming_knn2_partial", "knn2_finalize",
     "fmat_prepare_k", "fmat_solve_k", "fmat_score_k", "fmat_finalize_k", "ransac_select_k",
     "pnp_prepare_k", "pnp_solve_k", "pnp_score_k", "pnp_finalize_k", "triangulate_k",
-    "ba_points_k", "ba_edges_k", "ba_final_k", "ba_schur_points_k", "ba_schur_tiles_k", "ba_schur_final_k", "ba_backsub_k", "pyramid2_k", "expand_pm1_k", "hamming_mfma_k", "pnp_score32_k" };
+    "ba_points_k", "ba_edges_k", "ba_final_k", "ba_schur_points_k", "ba_schur_tiles_k", "ba_schur_final_k", "ba_backsub_k", "pyramid2_k", "expand_pm1_k", "hamming_mfma_k", "pnp_score32_k", "fmat7_solve_k", "fmat7_lmeds_k" };
 
 int prof_begin(mslam_ctx* ctx, int kid)
 {

@@ -307,7 +307,18 @@ struct FmatArgs {
     // hypotheses [h_lo, h_hi) of this launch; state (optional): {niters, best, maxgood} per problem, the adaptive bound
     // carried from one range to the next -- blocks past it have nothing to contribute and return
     int h_lo, h_hi; int32_t* state;
+    // 7-point mode (mslam_fmat_ransac7): H counts matrices (3 per sample), models hold pixel-domain matrices, thr_b the inlier
+    // threshold of each problem (RANSAC: thr; LMedS: from the least median; 7 pairs: +inf), method as the ABI's
+    int mp7; int method; int H7; int lmeds_iters; double* thr_b; int32_t* best_cnt;
 };
+
+// which estimator cvFindFundamentalMat runs for a problem of M pairs: 1 RANSAC, 2 LMedS, 3 the 7 pairs solved directly
+__device__ __forceinline__ int fm7_method(int method, int M)
+{
+    if (M == 7) return 3;
+    if (method == 0) return M >= 15 ? 1 : 2;
+    return method;
+}
 
 __global__ __launch_bounds__(256)
 void fmat_prepare_k(FmatArgs a)
@@ -383,6 +394,262 @@ void fmat_solve_k(FmatArgs a)
         }
 }
 
+// ---- 7-point minimal solver (OpenCV's run7Point restated; the CPU restatement evaluates the same operations in the same order)
+__device__ __forceinline__ void cof3(const double* A, double* C)
+{
+    C[0] = A[4] * A[8] - A[5] * A[7]; C[1] = A[5] * A[6] - A[3] * A[8]; C[2] = A[3] * A[7] - A[4] * A[6];
+    C[3] = A[2] * A[7] - A[1] * A[8]; C[4] = A[0] * A[8] - A[2] * A[6]; C[5] = A[1] * A[6] - A[0] * A[7];
+    C[6] = A[1] * A[5] - A[2] * A[4]; C[7] = A[2] * A[3] - A[0] * A[5]; C[8] = A[0] * A[4] - A[1] * A[3];
+}
+
+__device__ double cubic_root(double a, double b, double c);
+
+// real roots of c3 x^3 + c2 x^2 + c1 x + c0 in cvSolveCubic's order (three real roots: smallest, largest, middle): monotone
+// Newton for one root, deflation in the stable direction, three Newton steps on the cubic for the other two.  + - * / sqrt only.
+__device__ int solve_cubic(double c3, double c2, double c1, double c0, double* r)
+{
+    r[0] = r[1] = r[2] = 0.0;
+    if (c3 == 0.0) {
+        if (c2 == 0.0) {
+            if (c1 == 0.0) return 0;
+            r[0] = -c0 / c1;
+            return 1;
+        }
+        double d = c1 * c1 - 4.0 * c2 * c0;
+        if (!(d >= 0.0)) return 0;
+        d = sqrt(d);
+        const double q = 1.0 / (2.0 * c2);
+        r[0] = (-c1 + d) * q;
+        r[1] = (-c1 - d) * q;
+        return 2;
+    }
+    const double a = c2 / c3, b = c1 / c3, c = c0 / c3;
+    const double x0 = cubic_root(a, b, c);
+    double p, q;
+    if (fabs(x0) * x0 * x0 > fabs(c)) { q = -c / x0; p = (q - b) / x0; }
+    else { p = a + x0; q = b + p * x0; }
+    const double disc = p * p - 4.0 * q;
+    if (!(disc >= 0.0)) { r[0] = x0; return 1; }
+    const double sq = sqrt(disc);
+    const double h = -0.5 * (p + (p >= 0.0 ? sq : -sq));
+    double x1 = h, x2 = h != 0.0 ? q / h : 0.0;
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        double x = k == 0 ? x1 : x2;
+        for (int it = 0; it < 3; it++) {
+            const double pv = ((x + a) * x + b) * x + c;
+            const double dp = (3.0 * x + 2.0 * a) * x + b;
+            if (dp == 0.0) break;
+            x = x - pv / dp;
+        }
+        if (k == 0) x1 = x; else x2 = x;
+    }
+    double lo = x0, mid = x1, hi = x2, t;
+    if (mid < lo) { t = lo; lo = mid; mid = t; }
+    if (hi < lo) { t = lo; lo = hi; hi = t; }
+    if (hi < mid) { t = mid; mid = hi; hi = t; }
+    r[0] = lo; r[1] = hi; r[2] = mid;
+    return 3;
+}
+
+// The 7 x 9 system of a lane lives in LDS, element-major (as null_8x9): Gauss-Jordan with complete pivoting leaves two free
+// columns, i.e. a basis (f1, f2) of the null space; det(lambda (f1 - f2) + f2) = 0 gives up to three matrices, scaled to F[8] = 1.
+__device__ int fmat_7point(double* __restrict__ s, int lane, double (*F)[9])
+{
+#define A_(r, c) s[((r) * 9 + (c)) * 64 + lane]
+    unsigned used_r = 0, used_c = 0;
+    int prow[7], pcol[7];
+    for (int k = 0; k < 7; k++) {
+        double best = -1.0;
+        int br = 0, bc = 0;
+        for (int r = 0; r < 7; r++) {
+            if ((used_r >> r) & 1u) continue;
+            for (int c = 0; c < 9; c++) {
+                if ((used_c >> c) & 1u) continue;
+                const double v = fabs(A_(r, c));
+                if (v > best) { best = v; br = r; bc = c; }
+            }
+        }
+        used_r |= 1u << br; used_c |= 1u << bc; prow[k] = br; pcol[k] = bc;
+        const double pv = A_(br, bc);
+        if (pv == 0.0) return 0;
+        double piv[9];
+#pragma unroll
+        for (int c = 0; c < 9; c++) piv[c] = A_(br, c);
+        for (int r = 0; r < 7; r++) {
+            if (r == br) continue;
+            const double m = A_(r, bc) / pv;
+#pragma unroll
+            for (int c = 0; c < 9; c++) {
+                const double nv = A_(r, c) - m * piv[c];
+                A_(r, c) = (c == bc) ? 0.0 : nv;
+            }
+        }
+    }
+    int cf[2] = { 0, 0 }, nf = 0;
+    for (int c = 0; c < 9; c++)
+        if (!((used_c >> c) & 1u)) { if (nf == 0) cf[0] = c; else cf[1] = c; nf++; }
+    double f[2][9];
+#pragma unroll
+    for (int v = 0; v < 2; v++) {
+        const int cfv = v == 0 ? cf[0] : cf[1];
+#pragma unroll
+        for (int c = 0; c < 9; c++) f[v][c] = (c == cfv) ? 1.0 : 0.0;
+        for (int k = 0; k < 7; k++) {
+            const double val = -A_(prow[k], cfv) / A_(prow[k], pcol[k]);
+#pragma unroll
+            for (int c = 0; c < 9; c++) f[v][c] = (c == pcol[k]) ? val : f[v][c];
+        }
+        double nn = 0.0;
+#pragma unroll
+        for (int c = 0; c < 9; c++) nn += f[v][c] * f[v][c];
+        nn = sqrt(nn);
+#pragma unroll
+        for (int c = 0; c < 9; c++) f[v][c] = f[v][c] / nn;
+    }
+#undef A_
+    double G[9], CG[9], C2[9];
+#pragma unroll
+    for (int c = 0; c < 9; c++) G[c] = f[0][c] - f[1][c];
+    cof3(G, CG); cof3(f[1], C2);
+    const double c3 = G[0] * CG[0] + G[1] * CG[1] + G[2] * CG[2];
+    const double c0 = f[1][0] * C2[0] + f[1][1] * C2[1] + f[1][2] * C2[2];
+    double c2 = 0.0, c1 = 0.0;
+#pragma unroll
+    for (int k = 0; k < 9; k++) { c2 += CG[k] * f[1][k]; c1 += C2[k] * G[k]; }
+    double roots[3];
+    const int n = solve_cubic(c3, c2, c1, c0, roots);
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        double lambda = roots[k], mu = 1.0;
+        const double sc = G[8] * roots[k] + f[1][8];
+        double f8 = 0.0;
+        if (fabs(sc) > DBL_EPSILON) { mu = 1.0 / sc; lambda = lambda * mu; f8 = 1.0; }
+#pragma unroll
+        for (int c = 0; c < 8; c++) F[k][c] = k < n ? G[c] * lambda + f[1][c] * mu : 0.0;
+        F[k][8] = k < n ? f8 : 0.0;
+    }
+    return n;
+}
+
+__global__ __launch_bounds__(64)
+void fmat7_solve_k(FmatArgs a)
+{
+    const int b = blockIdx.y;
+    const int h = blockIdx.x * 64 + threadIdx.x;
+    if (h >= a.H7) return;
+    const int M = a.M[b];
+    const double* x1 = a.x1 + (size_t)b * a.capM * 2;
+    const double* x2 = a.x2 + (size_t)b * a.capM * 2;
+    const int32_t* s = a.samples + ((size_t)b * a.H7 + h) * 7;
+    __shared__ double s_A[63 * 64];
+    const int lane = threadIdx.x;
+    bool valid = M >= 7;
+#pragma unroll
+    for (int k = 0; k < 7; k++) {
+        int i = s[k];
+        if (i < 0 || i >= M) { valid = false; i = 0; }
+        const double u1 = x1[2 * i], v1 = x1[2 * i + 1], u2 = x2[2 * i], v2 = x2[2 * i + 1];
+        const double row[9] = { u2 * u1, u2 * v1, u2, v2 * u1, v2 * v1, v2, u1, v1, 1.0 };
+#pragma unroll
+        for (int c = 0; c < 9; c++) s_A[(k * 9 + c) * 64 + lane] = row[c];
+    }
+    double F[3][9];
+    const int n = fmat_7point(s_A, lane, F);
+    double* mo = a.models + ((size_t)b * a.H + 3 * h) * 9;
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+#pragma unroll
+        for (int e = 0; e < 9; e++) mo[k * 9 + e] = (valid && k < n) ? F[k][e] : 0.0;   // all zero = no matrix
+}
+
+// OpenCV computeReprojError: max of the two squared point-to-epipolar-line distances, as float
+__device__ __forceinline__ float fmat_err_f(const double* F, double u1, double v1, double u2, double v2)
+{
+    double aa = fma(F[0], u1, fma(F[1], v1, F[2]));
+    double bb = fma(F[3], u1, fma(F[4], v1, F[5]));
+    double cc = fma(F[6], u1, fma(F[7], v1, F[8]));
+    double s2 = 1. / fma(aa, aa, bb * bb);
+    double d2 = fma(u2, aa, fma(v2, bb, cc));
+    aa = fma(F[0], u2, fma(F[3], v2, F[6]));
+    bb = fma(F[1], u2, fma(F[4], v2, F[7]));
+    cc = fma(F[2], u2, fma(F[5], v2, F[8]));
+    double s1 = 1. / fma(aa, aa, bb * bb);
+    double d1 = fma(u1, aa, fma(v1, bb, cc));
+    double e1 = d1 * d1 * s1, e2 = d2 * d2 * s2;
+    return (float)(e1 > e2 ? e1 : e2);
+}
+
+// runLMeDS / the direct 7-pair case: one wavefront per problem, a lane takes a matrix, sorts its (at most FM7_LMEDS_MAXM) errors
+// in LDS and keeps the least median; the winner is the first matrix with the least median, the inlier threshold follows from it.
+// Problems that runRANSAC owns only get their threshold written.
+constexpr int FM7_LMEDS_MAXM = 32;
+__global__ __launch_bounds__(64)
+void fmat7_lmeds_k(FmatArgs a)
+{
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int M = a.M[b];
+    const int method = fm7_method(a.method, M);
+    if (method == 1 || M < 7) {
+        if (lane == 0) { a.thr_b[b] = a.thr; if (M < 7) a.best[b] = -1; }
+        return;
+    }
+    const double* pts = a.pts + (size_t)b * a.capM * 4;
+    if (method == 3) {   // exactly 7 pairs: the first matrix of sample 0, every pair is an inlier
+        if (lane == 0) {
+            bool any = false;
+            for (int e = 0; e < 9; e++) any |= a.models[(size_t)b * a.H * 9 + e] != 0.0;
+            a.best[b] = any ? 0 : -1;
+            a.thr_b[b] = INFINITY;
+        }
+        return;
+    }
+    __shared__ float s_err[FM7_LMEDS_MAXM * 64];
+    const int Mc = min(M, FM7_LMEDS_MAXM);   // (the host refuses LMedS for more pairs than this)
+    double my_med = DBL_MAX;
+    int my_best = -1;
+    const int nmod = 3 * min(a.lmeds_iters, a.H7);
+    for (int v0 = 0; v0 < nmod; v0 += 64) {
+        const int v = v0 + lane;
+        if (v < nmod) {
+            double F[9];
+            bool any = false;
+#pragma unroll
+            for (int e = 0; e < 9; e++) { F[e] = a.models[((size_t)b * a.H + v) * 9 + e]; any |= F[e] != 0.0; }
+            if (any) {
+                for (int i = 0; i < Mc; i++) {   // insertion sort, ascending; a NaN error sorts as +inf
+                    float e = fmat_err_f(F, pts[4 * i], pts[4 * i + 1], pts[4 * i + 2], pts[4 * i + 3]);
+                    e = e == e ? e : INFINITY;
+                    int j = i;
+                    while (j > 0 && s_err[(j - 1) * 64 + lane] > e) { s_err[j * 64 + lane] = s_err[(j - 1) * 64 + lane]; j--; }
+                    s_err[j * 64 + lane] = e;
+                }
+                const double median = (Mc & 1) ? (double)s_err[(Mc / 2) * 64 + lane]
+                                               : (double)(s_err[(Mc / 2 - 1) * 64 + lane] + s_err[(Mc / 2) * 64 + lane]) * 0.5;
+                if (median < my_med) { my_med = median; my_best = v; }
+            }
+        }
+    }
+    // first matrix with the least median: (median, index) lexicographic minimum over the lanes
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double om = __shfl_xor(my_med, o);
+        const int ob = __shfl_xor(my_best, o);
+        const bool take = ob >= 0 && (my_best < 0 || om < my_med || (om == my_med && ob < my_best));
+        if (take) { my_med = om; my_best = ob; }
+    }
+    if (lane == 0) {
+        a.best[b] = my_best;
+        double thr = a.thr;
+        if (my_best >= 0) {
+            double sigma = 2.5 * 1.4826 * (1 + 5. / (M - 7)) * sqrt(my_med);
+            sigma = sigma > 0.001 ? sigma : 0.001;
+            thr = sigma * sigma;
+        }
+        a.thr_b[b] = thr;
+    }
+}
+
 __device__ __forceinline__ bool fmat_inlier(const double* F, double u1, double v1, double u2, double v2, int metric, double thr)
 {
     if (metric == 0) { // getInlier (:715-763)
@@ -423,6 +690,7 @@ void fmat_score_k(FmatArgs a)
     if (a.state && h0 >= a.state[3 * b]) return; // past the adaptive bound (block-uniform)
     const int nh = min(FM_HPB, a.h_hi - h0);
     const int M = a.M[b];
+    if (a.mp7 && fm7_method(a.method, M) != 1) return;   // LMedS / direct problems are not scored by counts
     __shared__ double s_F[FM_HPB][9];
     __shared__ int s_cnt[FM_HPB];
     for (int i = tid; i < FM_HPB * 9; i += SCORE_THREADS) {
@@ -507,34 +775,36 @@ __device__ int ransac_update_iters(double p, double ep, int model_points, int ma
 __global__ __launch_bounds__(64)
 void ransac_select_k(const int32_t* __restrict__ counts, const int32_t* __restrict__ npts, int H, int sample_size,
                      double confidence, int32_t* __restrict__ best_out, int32_t* __restrict__ best_cnt_out,
-                     int h_lo, int h_hi, int32_t* __restrict__ state)
+                     int h_lo, int h_hi, int32_t* __restrict__ state, int mpi)
 {
+    // mpi: candidates per RANSAC iteration (1; 3 for the 7-point solver, whose samples yield up to three matrices: runRANSAC tests
+    // its bound once per sample and takes every matrix of the sample as a candidate).  Indices and H count candidates.
     // state (optional): the scan continues over [h_lo, h_hi) from where the previous range left {niters, best, maxgood}
     const int b = blockIdx.x, lane = threadIdx.x;
     const int32_t* c = counts + (size_t)b * H;
     const int n_points = npts[b];
     const bool adaptive = confidence > 0. && confidence < 1.;
-    int niters = H, best = -1, maxgood = 0;
+    int niters = H / mpi, best = -1, maxgood = 0;
     if (state) { niters = state[3 * b]; best = state[3 * b + 1]; maxgood = state[3 * b + 2]; }
     // (eight chunks of 64 counts are fetched together: one memory latency per 512 counts instead of one per 64)
     constexpr int SEL_PF = 8;
-    for (int g0 = h_lo; g0 < niters && g0 < h_hi; g0 += 64 * SEL_PF) {
+    for (int g0 = h_lo; g0 < niters * mpi && g0 < h_hi; g0 += 64 * SEL_PF) {
       int vv[SEL_PF];
 #pragma unroll
       for (int u = 0; u < SEL_PF; u++) { const int i = g0 + 64 * u + lane; vv[u] = i < h_hi ? c[i] : -1; }
 #pragma unroll
       for (int u = 0; u < SEL_PF; u++) {
         const int i0 = g0 + 64 * u;
-        if (!(i0 < niters && i0 < h_hi)) break;
+        if (!(i0 < niters * mpi && i0 < h_hi)) break;
         const int i = i0 + lane;
         const int v = vv[u];
         int floor_ = maxgood > sample_size - 1 ? maxgood : sample_size - 1;
-        unsigned long long bal = __ballot(i < niters && v > floor_);
+        unsigned long long bal = __ballot(i < niters * mpi && v > floor_);
         while (bal) { // record breakers in index order
             const int j = __ffsll((long long)bal) - 1;
             bal &= bal - 1;
             const int it = i0 + j;
-            if (it >= niters) break;
+            if (it >= niters * mpi) break;
             const int good = __shfl(v, j);
             floor_ = maxgood > sample_size - 1 ? maxgood : sample_size - 1;
             if (good > floor_) {
@@ -602,21 +872,28 @@ void fmat_finalize_k(FmatArgs a)
     const double* x1 = a.x1 + (size_t)b * a.capM * 2;
     const double* x2 = a.x2 + (size_t)b * a.capM * 2;
     const double maxt = a.maxt[b];
+    const double thr = a.thr_b ? a.thr_b[b] : a.thr;
     int my = 0;
     for (int i = tid; i < M; i += 256) {
         double4 p = pts[i];
-        bool in = fmat_inlier(s_F, p.x, p.y, p.z, p.w, a.metric, a.thr);
+        bool in = fmat_inlier(s_F, p.x, p.y, p.z, p.w, a.metric, thr);
         status[i] = (uint8_t)in;
         my += in;
     }
     atomicAdd(&s_n, my);
     __syncthreads();
     const int n = s_n;
+    if (a.mp7 && n < 7) {   // runLMeDS: result = count >= modelPoints
+        for (int i = tid; i < M; i += 256) status[i] = 0;
+        if (tid < 9) Fout[tid] = 0.0;
+        if (tid == 0) { a.n_inliers[b] = 0; a.best[b] = -1; }
+        return;
+    }
     if (tid == 0) a.n_inliers[b] = n;
     if (a.refit == 0 || n < 8) {
         if (tid < 9) {
             const double t[3] = { 1.0 / maxt, 1.0 / maxt, 1.0 };
-            Fout[tid] = t[tid / 3] * a.models_s[((size_t)b * a.H + best) * 9 + tid] * t[tid % 3];
+            Fout[tid] = a.mp7 ? s_F[tid] : t[tid / 3] * a.models_s[((size_t)b * a.H + best) * 9 + tid] * t[tid % 3];
         }
         return;
     }
@@ -1765,7 +2042,7 @@ int mslam_fmat_ransac8_batch_dev(mslam_ctx* ctx, const double* x1, const double*
         a.h_lo = lo; a.h_hi = hi;
         LAUNCH(ctx, K_FMAT_SOLVE, fmat_solve_k, dim3((hi - lo + 63) / 64, B), dim3(64), 0, a);
         LAUNCH(ctx, K_FMAT_SCORE, fmat_score_k, dim3((hi - lo + FM_HPB - 1) / FM_HPB, B), dim3(SCORE_THREADS), 0, a);
-        LAUNCH(ctx, K_RANSAC_SELECT, ransac_select_k, dim3(B), dim3(64), 0, a.counts, M, H, 8, prm->confidence, best_h, (int32_t*)nullptr, lo, hi, a.state);
+        LAUNCH(ctx, K_RANSAC_SELECT, ransac_select_k, dim3(B), dim3(64), 0, a.counts, M, H, 8, prm->confidence, best_h, (int32_t*)nullptr, lo, hi, a.state, 1);
         lo = hi;
     }
     LAUNCH(ctx, K_FMAT_FINALIZE, fmat_finalize_k, dim3(B), dim3(256), 0, a);
@@ -1811,6 +2088,91 @@ int mslam_fmat_ransac8(mslam_ctx* ctx, const double* x1, const double* x2, int M
     return MSLAM_OK;
 }
 
+// findFundamentalMat(CV_FM_RANSAC) as the reference's live path calls it (src/CameraPoseEstimator.cpp:563): 7-point samples
+int mslam_fmat_ransac7_batch_dev(mslam_ctx* ctx, const double* x1, const double* x2, const int32_t* M, int capM,
+                                 const int32_t* samples, int H, int B, const mslam_fmat_params* prm, int method, double* F,
+                                 uint8_t* status, int32_t* inlier_counts, int32_t* best_model, int32_t* n_inliers)
+{
+    if (!ctx || !x1 || !x2 || !M || !samples || !prm || !F || !status || !best_model || !n_inliers || capM < 7 || H < 1 || B < 1 ||
+        prm->metric != 1 || (prm->refit != 0 && prm->refit != 2) || !(prm->threshold > 0) || method < 0 || method > 2 ||
+        (method == 2 && capM > FM7_LMEDS_MAXM) || (size_t)H * 3 > 0x7fffffffu)
+        return MSLAM_ERR_INVALID;
+    MSLAM_TRY(ctx_set_device(ctx));
+    const int HM = 3 * H;
+    size_t bytes = 0;
+    auto reserve = [&](size_t n) { bytes = align_up(bytes, 256); size_t o = bytes; bytes += n; return o; };
+    const size_t o_pts = reserve(sizeof(double) * 4 * (size_t)B * capM), o_maxt = reserve(sizeof(double) * B),
+                 o_mod = reserve(sizeof(double) * 9 * (size_t)B * HM), o_cnt = reserve(sizeof(int32_t) * (size_t)B * HM),
+                 o_thr = reserve(sizeof(double) * B);
+    void* scr = nullptr;
+    MSLAM_TRY(ctx_scratch(ctx, bytes, &scr));
+    char* base = (char*)scr;
+    FmatArgs a{};
+    a.x1 = x1; a.x2 = x2; a.M = M; a.capM = capM; a.samples = samples; a.H = HM; a.B = B;
+    a.metric = 1; a.thr = prm->threshold * prm->threshold; a.confidence = prm->confidence; a.refit = prm->refit;
+    a.pts = (double*)(base + o_pts); a.maxt = (double*)(base + o_maxt); a.models = (double*)(base + o_mod); a.models_s = a.models;
+    a.counts = inlier_counts ? inlier_counts : (int32_t*)(base + o_cnt);
+    a.best = best_model; a.F = F; a.status = status; a.n_inliers = n_inliers;
+    a.state = nullptr; a.h_lo = 0; a.h_hi = HM;
+    a.mp7 = 1; a.method = method; a.H7 = H; a.thr_b = (double*)(base + o_thr);
+    {   // runLMeDS's iteration count: confidence outside (0, 1) reads 0.99, outlier ratio 0.45, at least 3, at most the samples given
+        double conf = prm->confidence;
+        if (conf < DBL_EPSILON || conf > 1 - DBL_EPSILON) conf = 0.99;
+        long it = lrint(log(1 - conf) / log(1 - pow(1 - 0.45, 7.0)));
+        it = it > 3 ? it : 3;
+        a.lmeds_iters = (int)(it < H ? it : H);
+    }
+    LAUNCH(ctx, K_FMAT_PREPARE, fmat_prepare_k, dim3(B), dim3(256), 0, a);
+    LAUNCH(ctx, K_FMAT7_SOLVE, fmat7_solve_k, dim3((H + 63) / 64, B), dim3(64), 0, a);
+    // (counts of problems the score kernel leaves -- LMedS / direct -- must not be garbage if the caller reads them)
+    HIP_TRY(ctx, hipMemsetAsync(a.counts, 0, sizeof(int32_t) * (size_t)B * HM, ctx->stream));
+    LAUNCH(ctx, K_FMAT_SCORE, fmat_score_k, dim3((HM + FM_HPB - 1) / FM_HPB, B), dim3(SCORE_THREADS), 0, a);
+    LAUNCH(ctx, K_RANSAC_SELECT, ransac_select_k, dim3(B), dim3(64), 0, a.counts, M, HM, 7, prm->confidence, best_model, (int32_t*)nullptr, 0, HM,
+           (int32_t*)nullptr, 3);
+    LAUNCH(ctx, K_FMAT7_LMEDS, fmat7_lmeds_k, dim3(B), dim3(64), 0, a);
+    LAUNCH(ctx, K_FMAT_FINALIZE, fmat_finalize_k, dim3(B), dim3(256), 0, a);
+    HIP_TRY(ctx, hipGetLastError());
+    return MSLAM_OK;
+}
+
+int mslam_fmat_ransac7(mslam_ctx* ctx, const double* x1, const double* x2, int M, const int32_t* samples, int H,
+                       const mslam_fmat_params* prm, int method, double F[9], uint8_t* status, int32_t* inlier_counts,
+                       int* best_model, int* n_inliers)
+{
+    if (!ctx || !x1 || !x2 || !samples || !prm || !F || !status) return MSLAM_ERR_INVALID;
+    if (M < 7 || H < 1) return MSLAM_ERR_TOO_FEW;
+    MSLAM_TRY(ctx_set_device(ctx));
+    size_t bytes = 0;
+    auto reserve = [&](size_t n) { bytes = align_up(bytes, 256); size_t o = bytes; bytes += n; return o; };
+    const size_t o_x1 = reserve(sizeof(double) * 2 * M), o_x2 = reserve(sizeof(double) * 2 * M), o_M = reserve(16),
+                 o_s = reserve(sizeof(int32_t) * 7 * (size_t)H), o_F = reserve(72), o_st = reserve(M),
+                 o_c = reserve(sizeof(int32_t) * 3 * (size_t)H), o_b = reserve(16);
+    void* stg = nullptr;
+    MSLAM_TRY(ctx_stage(ctx, bytes, &stg));
+    char* base = (char*)stg;
+    hipStream_t st = ctx->stream;
+    int32_t hM = M;
+    HIP_TRY(ctx, hipMemcpyAsync(base + o_x1, x1, sizeof(double) * 2 * M, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(base + o_x2, x2, sizeof(double) * 2 * M, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(base + o_M, &hM, 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(base + o_s, samples, sizeof(int32_t) * 7 * (size_t)H, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    int32_t* db = (int32_t*)(base + o_b);
+    MSLAM_TRY(mslam_fmat_ransac7_batch_dev(ctx, (double*)(base + o_x1), (double*)(base + o_x2), (int32_t*)(base + o_M), M,
+                                           (int32_t*)(base + o_s), H, 1, prm, method, (double*)(base + o_F), (uint8_t*)(base + o_st),
+                                           (int32_t*)(base + o_c), db, db + 1));
+    int32_t hb[2] = { -1, 0 };
+    HIP_TRY(ctx, hipMemcpyAsync(hb, db, 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipMemcpyAsync(F, base + o_F, 72, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipMemcpyAsync(status, base + o_st, M, hipMemcpyDeviceToHost, st));
+    if (inlier_counts) HIP_TRY(ctx, hipMemcpyAsync(inlier_counts, base + o_c, sizeof(int32_t) * 3 * (size_t)H, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    if (best_model) *best_model = hb[0];
+    if (n_inliers) *n_inliers = hb[1];
+    if (hb[0] < 0) return MSLAM_ERR_DEGENERATE;
+    return MSLAM_OK;
+}
+
 int mslam_pnp_ransac_batch_dev(mslam_ctx* ctx, const double* X, const double* x, const int32_t* P, int capP,
                                const double* K, const double* dist, const int32_t* samples, int H, int B,
                                const mslam_pnp_params* prm, double* Rt, double* rvec, double* tvec, uint8_t* inliers,
@@ -1841,7 +2203,7 @@ int mslam_pnp_ransac_batch_dev(mslam_ctx* ctx, const double* X, const double* x,
     // each of the two scoring kernels leaves at once the problems the other one owns (distortion or not is device data)
     if (a.f32_tier) LAUNCH(ctx, K_PNP_SCORE32, pnp_score32_k, dim3((H + PNP_HPB - 1) / PNP_HPB, B), dim3(SCORE_THREADS), 0, a);
     LAUNCH(ctx, K_PNP_SCORE, pnp_score_k, dim3((H + PNP_HPB - 1) / PNP_HPB, B), dim3(SCORE_THREADS), 0, a);
-    LAUNCH(ctx, K_RANSAC_SELECT, ransac_select_k, dim3(B), dim3(64), 0, a.counts, P, H, 4, prm->confidence, best_h, a.best_cnt, 0, H, (int32_t*)nullptr);
+    LAUNCH(ctx, K_RANSAC_SELECT, ransac_select_k, dim3(B), dim3(64), 0, a.counts, P, H, 4, prm->confidence, best_h, a.best_cnt, 0, H, (int32_t*)nullptr, 1);
     LAUNCH(ctx, K_PNP_FINALIZE, pnp_finalize_k, dim3(B), dim3(FIN_THREADS), 0, a);
     HIP_TRY(ctx, hipGetLastError());
     return MSLAM_OK;

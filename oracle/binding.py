@@ -267,3 +267,30 @@ def ba_schur(pr, lam: float):
     S = np.zeros((n6, n6)); bs = np.zeros(n6); x = np.zeros(n6 + 3 * pr["n_points"])
     rc = lib().orc_ba_schur(C.byref(ps), C.c_double(lam), _p(S, f64p), _p(bs, f64p), _p(x, f64p))
     return dict(rc=rc, S=S, bs=bs, x=x)
+
+
+def solve_cubic(c3, c2, c1, c0):
+    r = np.zeros(3)
+    lib().orc_solve_cubic.argtypes = [C.c_double] * 4 + [f64p]
+    n = lib().orc_solve_cubic(c3, c2, c1, c0, _p(r, f64p))
+    return r[:n]
+
+
+def fmat_7point(x1, x2, sel=None):
+    x1 = np.ascontiguousarray(x1, np.float64); x2 = np.ascontiguousarray(x2, np.float64)
+    F = np.zeros(27)
+    selp = None if sel is None else _p(np.ascontiguousarray(sel, np.int32), i32p)
+    n = lib().orc_fmat_7point(_p(x1, f64p), _p(x2, f64p), selp, _p(F, f64p))
+    return F.reshape(3, 3, 3)[:n]
+
+
+def fmat_ransac7(x1, x2, samples, params: FmatParams, method: int = 0):
+    """findFundamentalMat(CV_FM_RANSAC) with 7-point samples (H x 7); method 0 = OpenCV's choice by the number of pairs."""
+    x1 = np.ascontiguousarray(x1, np.float64); x2 = np.ascontiguousarray(x2, np.float64)
+    samples = np.ascontiguousarray(samples, np.int32)
+    M, H = x1.shape[0], samples.shape[0]
+    F = np.zeros(9); status = np.zeros(M, np.uint8); counts = np.zeros(3 * H, np.int32)
+    best, ninl = C.c_int(-1), C.c_int(0)
+    rc = lib().orc_fmat_ransac7(_p(x1, f64p), _p(x2, f64p), M, _p(samples, i32p), H, C.byref(params), method, _p(F, f64p),
+                                _p(status, u8p), _p(counts, i32p), C.byref(best), C.byref(ninl))
+    return dict(rc=rc, F=F.reshape(3, 3), status=status, counts=counts.reshape(H, 3), best_model=best.value, n_inliers=ninl.value)

@@ -278,6 +278,251 @@ int orc_fmat_ransac8(const double* x1, const double* x2, int M, const int32_t* s
     return rc;
 }
 
+/* ---- the live path of computeFundamentalMatrix (:563): findFundamentalMat(CV_FM_RANSAC, 3.0, 0.85) ----------------
+ * OpenCV 2.4.13 (absent here; restated from its published algorithm, PARITY UNPINNED): 7-point minimal samples
+ * (CvFMEstimator::run7Point: the two-dimensional null space of the 7 x 9 system, det(lambda f1 + (1 - lambda) f2) = 0,
+ * up to three matrices per sample, each scaled to F[8] = 1), every matrix of a sample scored by computeReprojError,
+ * runRANSAC's record/iteration-bound loop when there are at least 15 pairs and runLMeDS (least median of the errors,
+ * inlier threshold from the median) below that; exactly 7 pairs are solved directly.
+ * Stated differences, none observable in exact arithmetic: the null space comes from Gauss-Jordan elimination with
+ * complete pivoting instead of an SVD (any basis of the null space gives the same matrices), the cubic is solved by a
+ * monotone Newton iteration plus deflation instead of acos / cos / cbrt (so that CPU and GPU agree operation for
+ * operation), with the roots emitted in cvSolveCubic's order for three real roots (smallest, largest, middle). */
+
+/* cofactors: det(A + t B) = det A + t sum(cof(A) . B) + t^2 sum(cof(B) . A) + t^3 det B */
+static void cof3(const double A[9], double C[9])
+{
+    C[0] = A[4] * A[8] - A[5] * A[7]; C[1] = A[5] * A[6] - A[3] * A[8]; C[2] = A[3] * A[7] - A[4] * A[6];
+    C[3] = A[2] * A[7] - A[1] * A[8]; C[4] = A[0] * A[8] - A[2] * A[6]; C[5] = A[1] * A[6] - A[0] * A[7];
+    C[6] = A[1] * A[5] - A[2] * A[4]; C[7] = A[2] * A[3] - A[0] * A[5]; C[8] = A[0] * A[4] - A[1] * A[3];
+}
+
+/* a real root of x^3 + a x^2 + b x + c (the same monotone Newton iteration as the P3P solver's) */
+static double cubic_root_m(double a, double b, double c)
+{
+    double xi = -a / 3.0;
+    double pi = ((xi + a) * xi + b) * xi + c;
+    if (pi == 0.0) return xi;
+    double m = fabs(a) > fabs(b) ? fabs(a) : fabs(b);
+    m = m > fabs(c) ? m : fabs(c);
+    double x = pi > 0.0 ? -(1.0 + m) : (1.0 + m);
+    for (int it = 0; it < 100; it++) {
+        double p = ((x + a) * x + b) * x + c;
+        double dp = (3.0 * x + 2.0 * a) * x + b;
+        if (dp == 0.0) break;
+        double xn = x - p / dp;
+        double dx = fabs(xn - x);
+        x = xn;
+        if (dx <= 1e-15 * fabs(xn) + 1e-300) break;
+    }
+    return x;
+}
+
+/* real roots of c3 x^3 + c2 x^2 + c1 x + c0, in cvSolveCubic's order; returns their number (0..3) */
+int orc_solve_cubic(double c3, double c2, double c1, double c0, double r[3])
+{
+    if (c3 == 0.0) {
+        if (c2 == 0.0) {
+            if (c1 == 0.0) return 0;
+            r[0] = -c0 / c1;
+            return 1;
+        }
+        double d = c1 * c1 - 4.0 * c2 * c0;
+        if (!(d >= 0.0)) return 0;
+        d = sqrt(d);
+        double q = 1.0 / (2.0 * c2);
+        r[0] = (-c1 + d) * q;
+        r[1] = (-c1 - d) * q;
+        return 2;
+    }
+    const double a = c2 / c3, b = c1 / c3, c = c0 / c3;
+    const double x0 = cubic_root_m(a, b, c);
+    /* the deflated quadratic x^2 + p x + q: forward division when x0 is the small root, backward when it is the large one
+     * (each is the stable direction; the other loses the small coefficients to cancellation) */
+    double p, q;
+    if (fabs(x0) * x0 * x0 > fabs(c)) { q = -c / x0; p = (q - b) / x0; }
+    else { p = a + x0; q = b + p * x0; }
+    const double disc = p * p - 4.0 * q;
+    if (!(disc >= 0.0)) { r[0] = x0; return 1; }
+    const double sq = sqrt(disc);
+    const double h = -0.5 * (p + (p >= 0.0 ? sq : -sq));
+    double x12[2] = { h, h != 0.0 ? q / h : 0.0 };
+    for (int k = 0; k < 2; k++)   /* three Newton steps on the cubic itself */
+        for (int it = 0; it < 3; it++) {
+            const double x = x12[k];
+            const double pv = ((x + a) * x + b) * x + c;
+            const double dp = (3.0 * x + 2.0 * a) * x + b;
+            if (dp == 0.0) break;
+            x12[k] = x - pv / dp;
+        }
+    double x1 = x12[0], x2 = x12[1];
+    /* ascending, then (smallest, largest, middle) */
+    double lo = x0, mid = x1, hi = x2, t;
+    if (mid < lo) { t = lo; lo = mid; mid = t; }
+    if (hi < lo) { t = lo; lo = hi; hi = t; }
+    if (hi < mid) { t = mid; mid = hi; hi = t; }
+    r[0] = lo; r[1] = hi; r[2] = mid;
+    return 3;
+}
+
+/* run7Point on the pairs sel[0..6] (pixel coordinates): up to three matrices (row-major, 9 doubles each) */
+int orc_fmat_7point(const double* x1, const double* x2, const int32_t* sel, double F[27])
+{
+    double A[63];
+    for (int k = 0; k < 7; k++) {
+        const int i = sel ? sel[k] : k;
+        const double u1 = x1[2 * i], v1 = x1[2 * i + 1], u2 = x2[2 * i], v2 = x2[2 * i + 1];
+        double* r = A + 9 * k;
+        r[0] = u2 * u1; r[1] = u2 * v1; r[2] = u2; r[3] = v2 * u1; r[4] = v2 * v1; r[5] = v2; r[6] = u1; r[7] = v1; r[8] = 1.0;
+    }
+    int used_r[7] = { 0 }, used_c[9] = { 0 }, prow[7], pcol[7];
+    for (int k = 0; k < 7; k++) {
+        double best = -1.0;
+        int br = 0, bc = 0;
+        for (int r = 0; r < 7; r++) {
+            if (used_r[r]) continue;
+            for (int c = 0; c < 9; c++) {
+                if (used_c[c]) continue;
+                const double v = fabs(A[r * 9 + c]);
+                if (v > best) { best = v; br = r; bc = c; }
+            }
+        }
+        used_r[br] = 1; used_c[bc] = 1; prow[k] = br; pcol[k] = bc;
+        const double pv = A[br * 9 + bc];
+        if (pv == 0.0) return 0;
+        for (int r = 0; r < 7; r++) {
+            if (r == br) continue;
+            const double m = A[r * 9 + bc] / pv;
+            for (int c = 0; c < 9; c++) A[r * 9 + c] = (c == bc) ? 0.0 : A[r * 9 + c] - m * A[br * 9 + c];
+        }
+    }
+    int cf[2], nf = 0;
+    for (int c = 0; c < 9; c++) if (!used_c[c]) cf[nf++] = c;
+    double f[2][9];
+    for (int v = 0; v < 2; v++) {
+        for (int c = 0; c < 9; c++) f[v][c] = 0.0;
+        f[v][cf[v]] = 1.0;
+        for (int k = 0; k < 7; k++) f[v][pcol[k]] = -A[prow[k] * 9 + cf[v]] / A[prow[k] * 9 + pcol[k]];
+        double nn = 0.0;
+        for (int c = 0; c < 9; c++) nn += f[v][c] * f[v][c];
+        nn = sqrt(nn);
+        for (int c = 0; c < 9; c++) f[v][c] = f[v][c] / nn;
+    }
+    /* F(lambda) = lambda G + f2 with G = f1 - f2 */
+    double G[9], CG[9], C2[9];
+    const double* f2 = f[1];
+    for (int c = 0; c < 9; c++) G[c] = f[0][c] - f2[c];
+    cof3(G, CG); cof3(f2, C2);
+    double c3 = G[0] * CG[0] + G[1] * CG[1] + G[2] * CG[2];
+    double c0 = f2[0] * C2[0] + f2[1] * C2[1] + f2[2] * C2[2];
+    double c2 = 0.0, c1 = 0.0;
+    for (int k = 0; k < 9; k++) { c2 += CG[k] * f2[k]; c1 += C2[k] * G[k]; }
+    double roots[3];
+    const int n = orc_solve_cubic(c3, c2, c1, c0, roots);
+    for (int k = 0; k < n; k++) {
+        double lambda = roots[k], mu = 1.0;
+        const double s = G[8] * roots[k] + f2[8];
+        double* Fk = F + 9 * k;
+        if (fabs(s) > DBL_EPSILON) { mu = 1.0 / s; lambda = lambda * mu; Fk[8] = 1.0; }
+        else Fk[8] = 0.0;
+        for (int c = 0; c < 8; c++) Fk[c] = G[c] * lambda + f2[c] * mu;
+    }
+    return n;
+}
+
+static int cmp_float(const void* a, const void* b)
+{
+    const float x = *(const float*)a, y = *(const float*)b;
+    return (x > y) - (x < y);
+}
+
+/* method: 0 = as cvFindFundamentalMat chooses (7 pairs: direct; >= 15: RANSAC; else LMedS), 1 = RANSAC, 2 = LMedS.
+ * samples: H x 7.  inlier_counts (optional): H x 3, RANSAC only (0 where a sample has fewer matrices).
+ * best_model = 3 * sample + root of the winner. */
+int orc_fmat_ransac7(const double* x1, const double* x2, int M, const int32_t* samples, int H,
+                     const orc_fmat_params* prm, int method, double F[9], uint8_t* status, int32_t* inlier_counts,
+                     int* best_model, int* n_inliers)
+{
+    if (M < 7 || H < 1) return -4;
+    if (method == 0) method = M == 7 ? 3 : (M >= 15 ? 1 : 2);
+    else if (M == 7) method = 3;
+    double Fb[9] = { 0 };
+    int best = -1;
+    double thr = prm->threshold * prm->threshold;
+    double* models = (double*)malloc(sizeof(double) * 27 * (size_t)H);
+    int* nm = (int*)malloc(sizeof(int) * (size_t)H);
+    for (int h = 0; h < H; h++) {
+        int ok = 1;
+        for (int k = 0; k < 7; k++) if (samples[7 * h + k] < 0 || samples[7 * h + k] >= M) ok = 0;
+        nm[h] = ok ? orc_fmat_7point(x1, x2, samples + 7 * h, models + 27 * h) : 0;
+    }
+    if (method == 3) { /* exactly 7 pairs: the first matrix of sample 0, every pair is an inlier */
+        if (nm[0] > 0) { best = 0; thr = INFINITY; }
+    } else if (method == 1) {
+        int32_t* counts = inlier_counts ? inlier_counts : (int32_t*)malloc(sizeof(int32_t) * 3 * (size_t)H);
+        for (int h = 0; h < H; h++)
+            for (int k = 0; k < 3; k++) {
+                int c = 0;
+                if (k < nm[h])
+                    for (int i = 0; i < M; i++) c += orc_fmat_error(models + 27 * h + 9 * k, x1 + 2 * i, x2 + 2 * i, 1) <= thr;
+                counts[3 * h + k] = c;
+            }
+        /* runRANSAC: the bound is tested once per sample, every matrix of the sample is a candidate */
+        int niters = H, maxgood = 0;
+        const int adaptive = prm->confidence > 0. && prm->confidence < 1.;
+        for (int it = 0; it < niters; it++)
+            for (int k = 0; k < 3; k++) {
+                const int good = counts[3 * it + k];
+                const int floor_ = maxgood > 6 ? maxgood : 6;
+                if (good > floor_) {
+                    best = 3 * it + k; maxgood = good;
+                    if (adaptive) niters = ransac_update_iters(prm->confidence, (double)(M - good) / M, 7, niters);
+                }
+            }
+        if (!inlier_counts) free(counts);
+    } else { /* runLMeDS */
+        double conf = prm->confidence;
+        if (conf < DBL_EPSILON || conf > 1 - DBL_EPSILON) conf = 0.99;
+        int niters = (int)lrint(log(1 - conf) / log(1 - pow(1 - 0.45, 7.0)));
+        niters = niters > 3 ? niters : 3;
+        niters = niters < H ? niters : H;
+        double min_median = DBL_MAX;
+        float* err = (float*)malloc(sizeof(float) * (size_t)M);
+        for (int it = 0; it < niters; it++)
+            for (int k = 0; k < nm[it]; k++) {
+                for (int i = 0; i < M; i++) {   /* (a NaN error -- a degenerate matrix -- sorts as +inf: its sign differs between machines) */
+                    const float e = (float)orc_fmat_error(models + 27 * it + 9 * k, x1 + 2 * i, x2 + 2 * i, 1);
+                    err[i] = e == e ? e : INFINITY;
+                }
+                qsort(err, (size_t)M, sizeof(float), cmp_float);
+                const double median = M % 2 != 0 ? (double)err[M / 2] : (double)(float)(err[M / 2 - 1] + err[M / 2]) * 0.5;
+                if (median < min_median) { min_median = median; best = 3 * it + k; }
+            }
+        free(err);
+        if (best >= 0) {
+            double sigma = 2.5 * 1.4826 * (1 + 5. / (M - 7)) * sqrt(min_median);
+            sigma = sigma > 0.001 ? sigma : 0.001;
+            thr = sigma * sigma;
+        }
+    }
+    int rc = 0, n = 0;
+    if (best >= 0) memcpy(Fb, models + 27 * (best / 3) + 9 * (best % 3), sizeof(Fb));
+    int32_t* sel = (int32_t*)malloc(sizeof(int32_t) * (size_t)M);
+    for (int i = 0; i < M; i++) {
+        const int in = best >= 0 && orc_fmat_error(Fb, x1 + 2 * i, x2 + 2 * i, 1) <= thr;
+        status[i] = (uint8_t)in;
+        if (in) sel[n++] = i;
+    }
+    if (best >= 0 && n < 7) { best = -1; for (int i = 0; i < M; i++) status[i] = 0; n = 0; } /* runLMeDS: result = count >= modelPoints */
+    if (best < 0) { memset(F, 0, sizeof(double) * 9); rc = -6; }
+    else if (prm->refit == 2 && n >= 8) rc = orc_fmat_8point_normalized(x1, x2, sel, n, F); /* the second call, CV_FM_8POINT (:585) */
+    else memcpy(F, Fb, sizeof(Fb));
+    free(sel); free(models); free(nm);
+    if (best_model) *best_model = best;
+    if (n_inliers) *n_inliers = n;
+    return rc;
+}
+
 /* TriangulateSinglePointFromTwoView (:86-128): DLT rows P(0)-P(2)x, P(1)-P(2)y for both views,
  * X = null vector of the 4x4 system (solveHLS), dehomogenised; front = z > 0 in both cameras */
 int orc_triangulate(const double* x1, const double* x2, int n, const double Rt1[12], const double Rt2[12],

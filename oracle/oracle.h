@@ -87,6 +87,12 @@ double orc_fmat_error(const double F[9], const double* p1, const double* p2, int
 int orc_fmat_ransac8(const double* x1, const double* x2, int M, const int32_t* samples, int H,
                      const orc_fmat_params* prm, double F[9], uint8_t* status, int32_t* inlier_counts,
                      int* best_h, int* n_inliers);
+/* findFundamentalMat(CV_FM_RANSAC) as the reference calls it (:563): 7-point minimal samples, up to 3 matrices each */
+int orc_solve_cubic(double c3, double c2, double c1, double c0, double r[3]);
+int orc_fmat_7point(const double* x1, const double* x2, const int32_t* sel, double F[27]);
+int orc_fmat_ransac7(const double* x1, const double* x2, int M, const int32_t* samples, int H,
+                     const orc_fmat_params* prm, int method, double F[9], uint8_t* status, int32_t* inlier_counts,
+                     int* best_model, int* n_inliers);
 /* adaptive-stop emulation shared by F and PnP: returns winning hypothesis over ordered counts */
 int orc_ransac_select(const int32_t* counts, int H, int n_points, int sample_size, double confidence, int* best_count);
 

@@ -389,3 +389,102 @@ def test_fmat_ranged_prefix_gives_the_full_pass_winner(ctx, outlier_frac, H):
     ref = ctx.fmat_ransac8(pr["x1"][:8], pr["x2"][:8], synth.sample_table(8, 100, 8, 1), p)
     assert few["best_h"] == ref["best_h"] and few["rc"] == ref["rc"]
     np.testing.assert_array_equal(few["F"], ref["F"])
+
+
+# ---- R8 as the reference's live path: findFundamentalMat(CV_FM_RANSAC) with 7-point samples (src/CameraPoseEstimator.cpp:563)
+@pytest.mark.parametrize("M,H,thr,refit,conf,seed", [(500, 600, 3.0, 2, 0.85, 11), (500, 600, 3.0, 0, 0.0, 12), (300, 400, 1.5, 2, 0.99, 13),
+                                                      (2000, 512, 3.0, 2, 0.0, 14), (15, 200, 3.0, 0, 0.85, 15)])
+def test_fmat_ransac7_matches_oracle(ctx, oracle, M, H, thr, refit, conf, seed):
+    tv = synth.two_view_problem(M, seed)
+    S = synth.sample_table(M, H, 7, seed + 100)
+    p = api.default_fmat_params()
+    p.threshold, p.refit, p.confidence = thr, refit, conf
+    g = ctx.fmat_ransac7(tv["x1"], tv["x2"], S, p)
+    o = oracle.fmat_ransac7(tv["x1"], tv["x2"], S, _fp(oracle, p))
+    assert g["rc"] == o["rc"] == 0
+    np.testing.assert_array_equal(g["counts"], o["counts"])
+    assert (g["counts"] > 0).sum() > H        # most samples give one matrix, many give three
+    assert g["best_model"] == o["best_model"] and g["n_inliers"] == o["n_inliers"]
+    np.testing.assert_array_equal(g["status"], o["status"])
+    _close(g["F"], o["F"], 1e-7)
+    if conf == 0.0 and M >= 300:   # every sample counted: the winner explains the rigid scene
+        assert (g["status"].astype(bool) == ~tv["outlier"]).mean() > 0.9
+
+
+@pytest.mark.parametrize("M,seed,noise", [(8, 31, 0.2), (9, 32, 0.3), (12, 33, 0.3), (14, 34, 0.5), (14, 35, 0.0)])
+def test_fmat_lmeds_below_15_pairs_matches_oracle(ctx, oracle, M, seed, noise):
+    """cvFindFundamentalMat runs runLMeDS when CV_FM_RANSAC is asked for with fewer than 15 pairs."""
+    tv = synth.two_view_problem(M, seed, noise=noise, outlier_frac=0.15)
+    S = synth.sample_table(M, 300, 7, seed)
+    p = api.default_fmat_params()
+    p.refit = 0
+    g = ctx.fmat_ransac7(tv["x1"], tv["x2"], S, p)
+    o = oracle.fmat_ransac7(tv["x1"], tv["x2"], S, _fp(oracle, p))
+    assert g["rc"] == o["rc"]
+    assert g["best_model"] == o["best_model"] and g["n_inliers"] == o["n_inliers"]
+    assert g["best_model"] < 3 * 124           # cvRound(log(0.15) / log(1 - 0.55^7)) = 124 samples are looked at
+    np.testing.assert_array_equal(g["status"], o["status"])
+    _close(g["F"], o["F"], 1e-9)
+    assert not g["counts"].any()               # no counts: the least median decides
+    # forcing the estimators: RANSAC on few pairs, LMedS where RANSAC would have run
+    for method in (1, 2):
+        g = ctx.fmat_ransac7(tv["x1"], tv["x2"], S, p, method=method)
+        o = oracle.fmat_ransac7(tv["x1"], tv["x2"], S, _fp(oracle, p), method)
+        assert g["rc"] == o["rc"] and g["best_model"] == o["best_model"] and g["n_inliers"] == o["n_inliers"]
+        np.testing.assert_array_equal(g["status"], o["status"])
+        if method == 1:
+            np.testing.assert_array_equal(g["counts"], o["counts"])
+
+
+def test_fmat_exactly_seven_pairs_and_invalid_requests(ctx, oracle):
+    tv = synth.two_view_problem(7, 41, noise=0.0, outlier_frac=0.0)
+    S = np.arange(7, dtype=np.int32)[None]
+    p = api.default_fmat_params()
+    g = ctx.fmat_ransac7(tv["x1"], tv["x2"], S, p)
+    o = oracle.fmat_ransac7(tv["x1"], tv["x2"], S, _fp(oracle, p))
+    assert g["rc"] == o["rc"] == 0 and g["best_model"] == o["best_model"] == 0 and g["n_inliers"] == 7 and g["status"].all()
+    _close(g["F"], o["F"], 1e-9)
+    x1 = np.c_[tv["x1"], np.ones(7)]; x2 = np.c_[tv["x2"], np.ones(7)]
+    assert np.abs(np.einsum("ni,ij,nj->n", x2, g["F"], x1)).max() < 1e-6 and abs(np.linalg.det(g["F"])) < 1e-12
+    with pytest.raises(api.MslamError):
+        ctx.fmat_ransac7(tv["x1"][:6], tv["x2"][:6], S, p)            # fewer than 7 pairs
+    p.metric = 0
+    with pytest.raises(api.MslamError):
+        ctx.fmat_ransac7(tv["x1"], tv["x2"], S, p)                     # OpenCV's estimator has one error measure
+    p = api.default_fmat_params()
+    big = synth.two_view_problem(40, 42)
+    with pytest.raises(api.MslamError):
+        ctx.fmat_ransac7(big["x1"], big["x2"], synth.sample_table(40, 50, 7, 1), p, method=2)   # LMedS: at most 32 pairs on the device
+    # samples with an index out of range yield no matrix instead of a fault
+    bad = synth.sample_table(40, 50, 7, 2); bad[::2, 3] = 4000
+    g = ctx.fmat_ransac7(big["x1"], big["x2"], bad, p)
+    o = oracle.fmat_ransac7(big["x1"], big["x2"], bad, _fp(oracle, p))
+    np.testing.assert_array_equal(g["counts"], o["counts"])
+    assert not g["counts"][::2].any() and g["best_model"] == o["best_model"]
+
+
+def test_fmat_ransac7_batch_mixes_estimators(ctx, oracle):
+    """One launch set over problems of 7, 12, 14, 15 and 300 pairs: each gets the estimator its size calls for."""
+    DeviceBuffer = api.DevBuf
+    sizes = [300, 12, 7, 15, 14, 200]
+    B, capM, H = len(sizes), 320, 256
+    x1 = np.zeros((B, capM, 2)); x2 = np.zeros((B, capM, 2)); S = np.zeros((B, H, 7), np.int32)
+    for b, m in enumerate(sizes):
+        tv = synth.two_view_problem(m, 50 + b, outlier_frac=0.2 if m >= 15 else 0.0)
+        x1[b, :m] = tv["x1"]; x2[b, :m] = tv["x2"]
+        S[b] = synth.sample_table(m, H, 7, 60 + b) if m > 7 else np.tile(np.arange(7, dtype=np.int32), (H, 1))
+    p = api.default_fmat_params()
+    d_x1, d_x2 = DeviceBuffer.from_array(ctx, x1), DeviceBuffer.from_array(ctx, x2)
+    d_M, d_S = DeviceBuffer.from_array(ctx, np.array(sizes, np.int32)), DeviceBuffer.from_array(ctx, S)
+    d_F, d_st = DeviceBuffer(ctx, B * 72), DeviceBuffer(ctx, B * capM)
+    d_c, d_b, d_n = DeviceBuffer(ctx, B * H * 3 * 4), DeviceBuffer(ctx, B * 4), DeviceBuffer(ctx, B * 4)
+    ctx.fmat_ransac7_batch_dev(d_x1.ptr, d_x2.ptr, d_M.ptr, capM, d_S.ptr, H, B, p, 0, d_F.ptr, d_st.ptr, d_c.ptr, d_b.ptr, d_n.ptr)
+    ctx.sync()
+    F = d_F.download(np.float64, (B, 3, 3)); st = d_st.download(np.uint8, (B, capM))
+    cnt = d_c.download(np.int32, (B, H, 3)); best = d_b.download(np.int32, (B,)); ninl = d_n.download(np.int32, (B,))
+    for b, m in enumerate(sizes):
+        o = oracle.fmat_ransac7(x1[b, :m], x2[b, :m], S[b], _fp(oracle, p))
+        assert best[b] == o["best_model"] and ninl[b] == o["n_inliers"], (b, m)
+        np.testing.assert_array_equal(st[b, :m], o["status"])
+        np.testing.assert_array_equal(cnt[b], o["counts"])
+        _close(F[b], o["F"], 1e-7)
