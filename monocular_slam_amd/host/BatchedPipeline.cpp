@@ -247,6 +247,7 @@ const cv::Mat& BatchedPipeline::descriptors(int stream, int frameIdx)
 void BatchedPipeline::matchFilterMany(int slotQ, const std::vector<int>& slotsT, float ratio, const std::vector<uint64_t>& seeds, Filtered& out)
 {
     const int B = streams(), cap = runner_->cap(), H = cpe_.fmatHypotheses, nb = (int)slotsT.size(), N = nb * B;
+    const int kf = cpe_.fmatSamplePoints == 7 ? 7 : 8;   // points per F sample (Stages.h)
     mslam_ctx* ctx = runner_->ctx();
     auto up256 = [](size_t v) { return (v + 255) & ~(size_t)255; };
     const size_t nl = (size_t)N * cap;
@@ -284,12 +285,13 @@ void BatchedPipeline::matchFilterMany(int slotQ, const std::vector<int>& slotsT,
         for (int k = 0; k < nb; k++) {
             const size_t o = (size_t)k * B * cap;
             chk(mslam_gather_matches_dev(ctx, runner_->kpsDev(slotQ), runner_->kpsDev(slotsT[(size_t)k]), cap, runner_->matchQueryDev() + o, runner_->matchTrainDev() + o,
-                                         runner_->matchCountDev() + (size_t)k * B, B, 8, dx1 + o * 2, dx2 + o * 2, dM + (size_t)k * B), "mslam_gather_matches_dev");
+                                         runner_->matchCountDev() + (size_t)k * B, B, kf, dx1 + o * 2, dx2 + o * 2, dM + (size_t)k * B), "mslam_gather_matches_dev");
         }
-        chk(mslam_sample_tables_dev(ctx, dM, dseed, H, 8, N, dS), "mslam_sample_tables_dev");
+        chk(mslam_sample_tables_dev(ctx, dM, dseed, H, kf, N, dS), "mslam_sample_tables_dev");
     }
     PhaseTimer pt(phaseMs[PH_FMAT]);
-    chk(mslam_fmat_ransac8_batch_dev(ctx, dx1, dx2, dM, cap, dS, H, N, &cpe_.fmat, dF, dst, nullptr, dbest, dninl), "mslam_fmat_ransac8_batch_dev");
+    if (kf == 7) chk(mslam_fmat_ransac7_batch_dev(ctx, dx1, dx2, dM, cap, dS, H, N, &cpe_.fmat, 0, dF, dst, nullptr, dbest, dninl), "mslam_fmat_ransac7_batch_dev");
+    else chk(mslam_fmat_ransac8_batch_dev(ctx, dx1, dx2, dM, cap, dS, H, N, &cpe_.fmat, dF, dst, nullptr, dbest, dninl), "mslam_fmat_ransac8_batch_dev");
     // a match list holds at most as many entries as the query frame has features: only those columns of the cap-wide tables travel
     const size_t used = (size_t)std::min(cap, std::max(slotFeatures_[(size_t)slotQ], 1));
     chk(mslam_memcpy_d2h_2d_async(ctx, hp + h_q, 4 * (size_t)cap, runner_->matchQueryDev(), 4 * (size_t)cap, 4 * used, (size_t)N), "mslam_memcpy_d2h_2d_async");
@@ -306,7 +308,7 @@ void BatchedPipeline::matchFilterMany(int slotQ, const std::vector<int>& slotsT,
     const int32_t* best = (const int32_t*)(hp + h_b);
     out.rc.assign((size_t)N, MSLAM_OK);
     for (int q = 0; q < N; q++) {
-        if (out.count[q] < 8) out.rc[(size_t)q] = MSLAM_ERR_TOO_FEW;          // status of such a set is not meaningful: inlier() says 0
+        if (out.count[q] < kf) out.rc[(size_t)q] = MSLAM_ERR_TOO_FEW;          // status of such a set is not meaningful: inlier() says 0
         else if (best[q] < 0) out.rc[(size_t)q] = MSLAM_ERR_DEGENERATE;
     }
 }

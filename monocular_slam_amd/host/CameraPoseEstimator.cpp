@@ -90,13 +90,16 @@ bool CameraPoseEstimator::computeFundamentalMatrix(const std::vector<Point2d>& p
     for (int i = 0; i < M; i++) { a[(size_t)i] = p1[(size_t)matches[(size_t)i].queryIdx]; b[(size_t)i] = p2[(size_t)matches[(size_t)i].trainIdx]; }
     status.assign((size_t)M, 0);
     in1.clear(); in2.clear();
-    if (M < 8) { lastStatus = MSLAM_ERR_TOO_FEW; return false; }
+    const int k = fmatSamplePoints == 7 ? 7 : 8;
+    if (M < k) { lastStatus = MSLAM_ERR_TOO_FEW; return false; }
     std::vector<double> x1, x2;
     flatten(a, x1); flatten(b, x2);
-    std::vector<int32_t> table = geom::sampleTable(M, fmatHypotheses, 8, tableSeed);
+    std::vector<int32_t> table = geom::sampleTable(M, fmatHypotheses, k, tableSeed);
     int best = -1, ninl = 0;
-    const int rc = mslam_fmat_ransac8(MslamRuntime::instance().ctx(), x1.data(), x2.data(), M, table.data(), fmatHypotheses, &fmat, F,
-                                      status.data(), nullptr, &best, &ninl);
+    const int rc = k == 7 ? mslam_fmat_ransac7(MslamRuntime::instance().ctx(), x1.data(), x2.data(), M, table.data(), fmatHypotheses, &fmat, 0, F,
+                                               status.data(), nullptr, &best, &ninl)
+                          : mslam_fmat_ransac8(MslamRuntime::instance().ctx(), x1.data(), x2.data(), M, table.data(), fmatHypotheses, &fmat, F,
+                                               status.data(), nullptr, &best, &ninl);
     if (rc != MSLAM_OK) { lastStatus = rc; std::fill(status.begin(), status.end(), 0); return false; }
     for (int i = 0; i < M; i++) if (status[(size_t)i]) { in1.push_back(a[(size_t)i]); in2.push_back(b[(size_t)i]); }
     return true;

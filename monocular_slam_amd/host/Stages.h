@@ -42,6 +42,10 @@ public:
     float ratioTracking = 0.8f;                     // matchFeatures default (:200, :409)
     mslam_fmat_params fmat;                         // metric 1, MAX_DISTANCE 3.0, CONFIDENCE 0.85, CV_FM_8POINT refit (:563,:585)
     int fmatHypotheses = 2000;                      // OpenCV's RANSAC iteration cap
+    // 8: hypotheses from the in-tree eight-point solver (computeFundamentalMatrix2, :596-786 -- north_star's "RANSAC eight-point");
+    // 7: OpenCV's own estimator behind findFundamentalMat(CV_FM_RANSAC) at :563 (mslam_fmat_ransac7: 7-point samples with up to
+    //    three matrices each, runLMeDS below 15 matches, the direct solution for exactly 7)
+    int fmatSamplePoints = 8;
     mslam_pnp_params pnp;                           // 8 px (OpenCV 2.4 solvePnPRansac default)
     int pnpHypotheses = 100;                        // OpenCV 2.4 default iterationsCount
     double distCoeff[8];                            // TUM freiburg1 coefficients hard-coded by the reference (:462-469)

@@ -55,18 +55,21 @@ def match_features(ob, d1, d2, ratio):
     return qi, ti
 
 
-def fundamental(ob, p1, p2, qi, ti, seed, H=2000):
+def fundamental(ob, p1, p2, qi, ti, seed, H=2000, k=8):
     fp = ob.fmat_default_params()   # metric 1, 3.0, 0.85, refit 2 == MAX_DISTANCE / CONFIDENCE / CV_FM_8POINT
     a, b = p1[qi], p2[ti]
-    if len(qi) < 8:
+    if len(qi) < k:
         return None, np.zeros(len(qi), np.uint8), a, b
-    r = ob.fmat_ransac8(a, b, sample_table(len(qi), H, 8, seed), fp)
+    if k == 7:   # CameraPoseEstimator::fmatSamplePoints = 7: OpenCV's own estimator (7-point samples, LMedS below 15 matches)
+        r = ob.fmat_ransac7(a, b, sample_table(len(qi), H, 7, seed), fp)
+    else:
+        r = ob.fmat_ransac8(a, b, sample_table(len(qi), H, 8, seed), fp)
     if r["rc"] != 0:
         return None, np.zeros(len(qi), np.uint8), a, b
     return r["F"], r["status"], a, b
 
 
-def run(ob, frames, K, nfeatures=500, seed=5, pnp_hyps=100, pnp_thr=8.0, dist=None):   # seed = CameraPoseEstimator::seed's default (Stages.h)
+def run(ob, frames, K, nfeatures=500, seed=5, pnp_hyps=100, pnp_thr=8.0, dist=None, fmat_points=8):   # seed = CameraPoseEstimator::seed's default (Stages.h)
     """Returns per-frame dict(kps, desc, Rt, map_idx) and the map (positions, observers)."""
     p = ob.orb_default_params(nfeatures)
     dist = np.zeros(8) if dist is None else dist
@@ -83,7 +86,7 @@ def run(ob, frames, K, nfeatures=500, seed=5, pnp_hyps=100, pnp_thr=8.0, dist=No
         if i == 1:
             pre = F[0]
             qi, ti = match_features(ob, pre["desc"], f["desc"], np.float32(0.85))
-            Fm, status, a, b = fundamental(ob, pre["pos"], f["pos"], qi, ti, seed + 1000 * i)
+            Fm, status, a, b = fundamental(ob, pre["pos"], f["pos"], qi, ti, seed + 1000 * i, k=fmat_points)
             f["Rt"] = pre["Rt"].copy()
             if Fm is None:
                 continue
@@ -103,7 +106,7 @@ def run(ob, frames, K, nfeatures=500, seed=5, pnp_hyps=100, pnp_thr=8.0, dist=No
         for j in range(i - 1, max(-1, i - 6), -1):
             pre = F[j]
             qi, ti = match_features(ob, f["desc"], pre["desc"], np.float32(0.8))
-            Fm, status, a, b = fundamental(ob, f["pos"], pre["pos"], qi, ti, seed + 1000 * i + (i - j))
+            Fm, status, a, b = fundamental(ob, f["pos"], pre["pos"], qi, ti, seed + 1000 * i + (i - j), k=fmat_points)
             qi, ti = qi[status == 1], ti[status == 1]
             cached.append((j, qi, ti))
             for cf, pf in zip(qi, ti):

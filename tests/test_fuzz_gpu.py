@@ -128,6 +128,25 @@ def test_fuzz_pnp_and_fmat(ctx, oracle, case):
         assert r["rc"] == g["rc"] and r["best_h"] == g["best_h"] and r["n_inliers"] == g["n_inliers"]
         np.testing.assert_array_equal(r["status"], g["status"])
         np.testing.assert_array_equal(r["F"], g["F"])
+    # the 7-point estimator on pixel coordinates: sizes around the RANSAC / LMedS switch at 15 pairs as often as large ones
+    M7 = int(rng.integers(7, 40)) if rng.random() < 0.5 else int(rng.integers(40, 1500))
+    H7 = int(rng.integers(1, 400))
+    tv7 = synth.two_view_problem(M7, 500 + case + SEED, noise=float(rng.uniform(0, 1.0)), outlier_frac=float(rng.uniform(0, 0.4)))
+    S7 = synth.sample_table(M7, H7, 7, 600 + case + SEED)
+    fp7 = api.default_fmat_params()
+    fp7.refit, fp7.threshold, fp7.confidence = int(rng.choice([0, 2])), float(rng.choice([0.5, 1.0, 3.0])), float(rng.choice([0.0, 0.85, 0.99]))
+    ofp7 = oracle.fmat_default_params()
+    for f, _ in api.FmatParams._fields_:
+        setattr(ofp7, f, getattr(fp7, f))
+    method = int(rng.choice([0, 0, 0, 1] + ([2] if M7 <= 32 else [])))
+    g = ctx.fmat_ransac7(tv7["x1"], tv7["x2"], S7, fp7, method=method)
+    o = oracle.fmat_ransac7(tv7["x1"], tv7["x2"], S7, ofp7, method)
+    assert g["rc"] == o["rc"], (M7, H7, method)
+    assert g["best_model"] == o["best_model"] and g["n_inliers"] == o["n_inliers"], (M7, H7, method)
+    np.testing.assert_array_equal(g["counts"], o["counts"])
+    np.testing.assert_array_equal(g["status"], o["status"])
+    if g["rc"] == 0:
+        assert np.abs(g["F"] - o["F"]).max() <= 1e-6 * max(1e-300, np.abs(o["F"]).max()), (M7, H7, method)
 
 
 @pytest.mark.parametrize("case", range(N))

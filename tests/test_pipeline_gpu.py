@@ -207,6 +207,35 @@ def test_batched_pipeline_equals_single_stream_pipelines(tmp_path, sequence):
     assert not np.array_equal(got[0]["poses"][2], got[1]["poses"][2])
 
 
+def test_pipeline_with_the_seven_point_estimator_of_the_live_reference_call(tmp_path, sequence, oracle):
+    """CameraPoseEstimator::fmatSamplePoints = 7 (--fmat7): findFundamentalMat(CV_FM_RANSAC) as OpenCV runs it
+    (src/CameraPoseEstimator.cpp:563) -- single-stream stages against the oracle-orchestrated flow, and the batched
+    pipeline against the single-stream one."""
+    frames, gt = sequence
+    flags = ("--no-dist", "--pnp-hyps", "256", "--pnp-thr", "3.0", "--fmat7")
+    poses, nfeat, pts, _ = _run_demo(tmp_path, frames, synth.K_TUM1, *flags)
+    import ref_pipeline
+    F, mp, obs = ref_pipeline.run(oracle, frames, synth.K_TUM1, pnp_hyps=256, pnp_thr=3.0, fmat_points=7)
+    for i in range(4):
+        np.testing.assert_allclose(poses[i], F[i]["Rt"], rtol=1e-6, atol=1e-8)
+    assert len(pts) == len(mp) and len(pts) > 100 and (pts[:, 3] == [len(o) for o in obs]).all()
+    np.testing.assert_allclose(pts[:, :3], mp, rtol=1e-5, atol=1e-7)
+    poses8, _, _, _ = _run_demo(tmp_path, frames, synth.K_TUM1, *flags[:-1])
+    assert not np.array_equal(poses8[1], poses[1])          # a different estimator, a different two-view initialisation
+    assert _rot_angle(poses[1][:, :3], gt[1][0]) < 1.0
+    p = tmp_path / "s7.bin"
+    _write_seq(p, frames, synth.K_TUM1)
+    out = tmp_path / "batched7.txt"
+    demo = os.path.join(ROOT, "monocular_slam_amd", "host", "mslam_batched_demo")
+    r = subprocess.run([demo, str(out), str(p), str(p), *flags], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    got = [np.array(line.split()[3:], float).reshape(3, 4) for line in open(out) if line.startswith("frame")]
+    assert len(got) == 8
+    for i in range(4):
+        np.testing.assert_array_equal(got[i], poses[i])
+        np.testing.assert_array_equal(got[4 + i], poses[i])
+
+
 def test_cpp_bench_binary_runs_the_batched_path():
     """mslam_bench (C++ host, MultiStreamRunner over the C ABI) at a small configuration: valid outputs, one JSON line."""
     import json
