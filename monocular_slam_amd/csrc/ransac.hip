@@ -339,7 +339,7 @@ void fmat_prepare_k(FmatArgs a)
     const double maxt = s_max[0];
     if (tid == 0) {
         a.maxt[b] = maxt;
-        if (a.state) { a.state[3 * b] = M >= 8 ? a.H : 0; a.state[3 * b + 1] = -1; a.state[3 * b + 2] = 0; }
+        if (a.state) { a.state[3 * b] = a.mp7 ? (M >= 7 ? a.H7 : 0) : (M >= 8 ? a.H : 0); a.state[3 * b + 1] = -1; a.state[3 * b + 2] = 0; }
     }
     double* pts = a.pts + (size_t)b * a.capM * 4;
     for (int i = tid; i < M; i += 256) {
@@ -536,8 +536,9 @@ __global__ __launch_bounds__(64)
 void fmat7_solve_k(FmatArgs a)
 {
     const int b = blockIdx.y;
-    const int h = blockIdx.x * 64 + threadIdx.x;
-    if (h >= a.H7) return;
+    const int h = a.h_lo / 3 + blockIdx.x * 64 + threadIdx.x;   // (h_lo, h_hi count matrices: three per sample)
+    if (a.state && a.h_lo / 3 + (int)blockIdx.x * 64 >= a.state[3 * b]) return; // past the adaptive bound (block-uniform)
+    if (h >= a.h_hi / 3) return;
     const int M = a.M[b];
     const double* x1 = a.x1 + (size_t)b * a.capM * 2;
     const double* x2 = a.x2 + (size_t)b * a.capM * 2;
@@ -687,7 +688,7 @@ __global__ __launch_bounds__(SCORE_THREADS)
 void fmat_score_k(FmatArgs a)
 {
     const int b = blockIdx.y, h0 = a.h_lo + blockIdx.x * FM_HPB, tid = threadIdx.x, lane = tid & 63;
-    if (a.state && h0 >= a.state[3 * b]) return; // past the adaptive bound (block-uniform)
+    if (a.state && h0 >= a.state[3 * b] * (a.mp7 ? 3 : 1)) return; // past the adaptive bound (block-uniform; the bound counts samples)
     const int nh = min(FM_HPB, a.h_hi - h0);
     const int M = a.M[b];
     if (a.mp7 && fm7_method(a.method, M) != 1) return;   // LMedS / direct problems are not scored by counts
@@ -2103,7 +2104,7 @@ int mslam_fmat_ransac7_batch_dev(mslam_ctx* ctx, const double* x1, const double*
     auto reserve = [&](size_t n) { bytes = align_up(bytes, 256); size_t o = bytes; bytes += n; return o; };
     const size_t o_pts = reserve(sizeof(double) * 4 * (size_t)B * capM), o_maxt = reserve(sizeof(double) * B),
                  o_mod = reserve(sizeof(double) * 9 * (size_t)B * HM), o_cnt = reserve(sizeof(int32_t) * (size_t)B * HM),
-                 o_thr = reserve(sizeof(double) * B);
+                 o_thr = reserve(sizeof(double) * B), o_state = reserve(sizeof(int32_t) * 3 * (size_t)B);
     void* scr = nullptr;
     MSLAM_TRY(ctx_scratch(ctx, bytes, &scr));
     char* base = (char*)scr;
@@ -2113,7 +2114,10 @@ int mslam_fmat_ransac7_batch_dev(mslam_ctx* ctx, const double* x1, const double*
     a.pts = (double*)(base + o_pts); a.maxt = (double*)(base + o_maxt); a.models = (double*)(base + o_mod); a.models_s = a.models;
     a.counts = inlier_counts ? inlier_counts : (int32_t*)(base + o_cnt);
     a.best = best_model; a.F = F; a.status = status; a.n_inliers = n_inliers;
-    a.state = nullptr; a.h_lo = 0; a.h_hi = HM;
+    // as in the eight-point form: unless every count is asked for, the samples go out in growing ranges and blocks past the adaptive
+    // bound return at once (LMedS problems keep the bound at H: their counts stay zero, their matrices are all formed)
+    const bool ranged = !inlier_counts && prm->confidence > 0. && prm->confidence < 1. && H > 64;
+    a.state = ranged ? (int32_t*)(base + o_state) : nullptr; a.h_lo = 0; a.h_hi = HM;
     a.mp7 = 1; a.method = method; a.H7 = H; a.thr_b = (double*)(base + o_thr);
     {   // runLMeDS's iteration count: confidence outside (0, 1) reads 0.99, outlier ratio 0.45, at least 3, at most the samples given
         double conf = prm->confidence;
@@ -2123,12 +2127,19 @@ int mslam_fmat_ransac7_batch_dev(mslam_ctx* ctx, const double* x1, const double*
         a.lmeds_iters = (int)(it < H ? it : H);
     }
     LAUNCH(ctx, K_FMAT_PREPARE, fmat_prepare_k, dim3(B), dim3(256), 0, a);
-    LAUNCH(ctx, K_FMAT7_SOLVE, fmat7_solve_k, dim3((H + 63) / 64, B), dim3(64), 0, a);
-    // (counts of problems the score kernel leaves -- LMedS / direct -- must not be garbage if the caller reads them)
+    // (counts of problems the score kernel leaves -- LMedS / direct -- are read by the select pass and perhaps by the caller: zero)
     HIP_TRY(ctx, hipMemsetAsync(a.counts, 0, sizeof(int32_t) * (size_t)B * HM, ctx->stream));
-    LAUNCH(ctx, K_FMAT_SCORE, fmat_score_k, dim3((HM + FM_HPB - 1) / FM_HPB, B), dim3(SCORE_THREADS), 0, a);
-    LAUNCH(ctx, K_RANSAC_SELECT, ransac_select_k, dim3(B), dim3(64), 0, a.counts, M, HM, 7, prm->confidence, best_model, (int32_t*)nullptr, 0, HM,
-           (int32_t*)nullptr, 3);
+    static const int bounds[] = { 64, 256, 1024 };
+    for (int r = 0, lo = 0; lo < H; r++) {
+        const int hi = (ranged && r < 3 && bounds[r] < H) ? bounds[r] : H;
+        a.h_lo = 3 * lo; a.h_hi = 3 * hi;
+        LAUNCH(ctx, K_FMAT7_SOLVE, fmat7_solve_k, dim3((hi - lo + 63) / 64, B), dim3(64), 0, a);
+        LAUNCH(ctx, K_FMAT_SCORE, fmat_score_k, dim3((3 * (hi - lo) + FM_HPB - 1) / FM_HPB, B), dim3(SCORE_THREADS), 0, a);
+        LAUNCH(ctx, K_RANSAC_SELECT, ransac_select_k, dim3(B), dim3(64), 0, a.counts, M, HM, 7, prm->confidence, best_model, (int32_t*)nullptr,
+               3 * lo, 3 * hi, a.state, 3);
+        lo = hi;
+    }
+    a.h_lo = 0; a.h_hi = HM;
     LAUNCH(ctx, K_FMAT7_LMEDS, fmat7_lmeds_k, dim3(B), dim3(64), 0, a);
     LAUNCH(ctx, K_FMAT_FINALIZE, fmat_finalize_k, dim3(B), dim3(256), 0, a);
     HIP_TRY(ctx, hipGetLastError());

@@ -147,6 +147,10 @@ def test_fuzz_pnp_and_fmat(ctx, oracle, case):
     np.testing.assert_array_equal(g["status"], o["status"])
     if g["rc"] == 0:
         assert np.abs(g["F"] - o["F"]).max() <= 1e-6 * max(1e-300, np.abs(o["F"]).max()), (M7, H7, method)
+    r = ctx.fmat_ransac7(tv7["x1"], tv7["x2"], S7, fp7, method=method, want_counts=False)   # hypothesis ranges
+    assert r["rc"] == g["rc"] and r["best_model"] == g["best_model"] and r["n_inliers"] == g["n_inliers"], (M7, H7, method)
+    np.testing.assert_array_equal(r["status"], g["status"])
+    np.testing.assert_array_equal(r["F"], g["F"])
 
 
 @pytest.mark.parametrize("case", range(N))

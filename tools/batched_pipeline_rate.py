@@ -18,7 +18,7 @@ for i, seed in enumerate((1003, 2007, 3011)):
         f.write(struct.pack("<4i", NF, 640, 480, 1)); f.write(np.ascontiguousarray(synth.K_TUM1, np.float64).tobytes()); f.write(frames.tobytes())
     paths.append(p)
 host = os.path.join(ROOT, "monocular_slam_amd", "host")
-flags = ["--no-dist", "--pnp-hyps", "256", "--pnp-thr", "3.0"]
+flags = ["--no-dist", "--pnp-hyps", "256", "--pnp-thr", "3.0"] + sys.argv[3:]   # e.g. --fmat7: the 7-point F estimator
 r = subprocess.run([os.path.join(host, "mslam_batched_demo"), os.path.join(tmp, "b.txt"), *paths, *flags, "--replicate", str(R), "--time"],
                    capture_output=True, text=True, timeout=900)
 print("batched:", r.stdout.strip().splitlines()[-1] if r.stdout.strip() else r.stderr[-500:])
