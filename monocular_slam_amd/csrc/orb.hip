@@ -669,16 +669,20 @@ void fast_nms_k(OrbDev od)
         if (tot) { // wave-uniform
             int base = 0;
             if (lane == 0) base = atomicAdd(&s_n1, tot);
-            base = __shfl(base, 0);
+            // byte offset of the wavefront's next entry, held on the scalar unit (the running sums of the slot counts are scalar
+            // additions, and a slot's address is one v_lshl_add_u32 of its rank)
+            uint32_t boff = 2u * (uint32_t)__builtin_amdgcn_readfirstlane(base);
+            asm volatile("" : "+s"(boff));   // (opaque: otherwise the factor 2 is pulled out of the sum again and every slot shifts twice)
+            uint8_t* const lb = reinterpret_cast<uint8_t*>(s_list);
 #pragma unroll
             for (int m = 0; m < FS_H / (FAST_THREADS / 32); m++) {
                 const int sy = ry + (FAST_THREADS / 32) * m;
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     // rank of this lane among the survivors of slot k: v_mbcnt_lo/hi take the lane mask straight from SGPRs
-                    const int rank_k = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal[m][k] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal[m][k], 0u));
-                    if (__builtin_amdgcn_inverse_ballot_w64(bal[m][k])) s_list[base + rank_k] = (uint16_t)(sy * FS_W + 4 * g + k);
-                    base += __popcll(bal[m][k]);
+                    const uint32_t rank_k = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal[m][k] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal[m][k], 0u));
+                    if (__builtin_amdgcn_inverse_ballot_w64(bal[m][k])) *reinterpret_cast<uint16_t*>(lb + (boff + 2u * rank_k)) = (uint16_t)(sy * FS_W + 4 * g + k);
+                    boff += 2u * (uint32_t)__popcll(bal[m][k]);
                 }
             }
         }
@@ -720,9 +724,10 @@ void fast_nms_k(OrbDev od)
             if (cm) { // wave-uniform
                 int base = 0;
                 if (lane == 0) base = atomicAdd(&s_nc, __popcll(cm));
-                base = __shfl(base, 0);
-                const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(cm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cm, 0u));
-                if (corner) s_list[CL0 + base + rank] = (uint16_t)i;
+                uint32_t boff = 2u * (uint32_t)(CL0 + __builtin_amdgcn_readfirstlane(base));   // (scalar, as in phase 1)
+                asm volatile("" : "+s"(boff));
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(cm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cm, 0u));
+                if (corner) *reinterpret_cast<uint16_t*>(reinterpret_cast<uint8_t*>(s_list) + (boff + 2u * rank)) = (uint16_t)i;
             }
         }
     }
