@@ -247,7 +247,11 @@ typedef struct {
     double reproj_thr;   /* 8.0 (OpenCV 2.4 default); BASELINE config C2 uses 2.0 */
     double confidence;   /* as mslam_fmat_params; <= 0 -> off */
     int refine_iters;    /* Gauss-Newton iterations on the inlier set (10); 0 = none */
-    int min_inliers;     /* fewer -> MSLAM_ERR_DEGENERATE (OpenCV: 100; default here 4) */
+    int min_inliers;     /* fewer inliers of the winner -> MSLAM_ERR_DEGENERATE (default 4; OpenCV keeps any winner with at least
+                            its 4 sample points) */
+    int stop_inliers;    /* OpenCV 2.4's minInliersCount (its default: 100): the scan over the ordered hypotheses ends at the
+                            first one whose inlier set holds at least this many points (PnPSolver::operator()'s early exit), so
+                            that one wins although a later one may count more; <= 0 (default): off, the best of all H wins */
 } mslam_pnp_params;
 void mslam_pnp_default_params(mslam_pnp_params* p);
 

@@ -776,8 +776,9 @@ __device__ int ransac_update_iters(double p, double ep, int model_points, int ma
 __global__ __launch_bounds__(64)
 void ransac_select_k(const int32_t* __restrict__ counts, const int32_t* __restrict__ npts, int H, int sample_size,
                      double confidence, int32_t* __restrict__ best_out, int32_t* __restrict__ best_cnt_out,
-                     int h_lo, int h_hi, int32_t* __restrict__ state, int mpi)
+                     int h_lo, int h_hi, int32_t* __restrict__ state, int mpi, int stop_count)
 {
+    // stop_count > 0: solvePnPRansac's early exit -- the scan ends at the first record that reaches this many inliers
     // mpi: candidates per RANSAC iteration (1; 3 for the 7-point solver, whose samples yield up to three matrices: runRANSAC tests
     // its bound once per sample and takes every matrix of the sample as a candidate).  Indices and H count candidates.
     // state (optional): the scan continues over [h_lo, h_hi) from where the previous range left {niters, best, maxgood}
@@ -812,6 +813,7 @@ void ransac_select_k(const int32_t* __restrict__ counts, const int32_t* __restri
                 best = it; maxgood = good;
                 if (adaptive && n_points > 0)
                     niters = ransac_update_iters(confidence, (double)(n_points - good) / n_points, sample_size, niters);
+                if (stop_count > 0 && maxgood >= stop_count) niters = min(niters, it / mpi + 1);   // nothing after this iteration is looked at
             }
         }
       }
@@ -2002,7 +2004,7 @@ void mslam_fmat_default_params(mslam_fmat_params* p)
 void mslam_pnp_default_params(mslam_pnp_params* p)
 {
     if (!p) return;
-    p->reproj_thr = 8.0; p->confidence = 0.0; p->refine_iters = 10; p->min_inliers = 4;
+    p->reproj_thr = 8.0; p->confidence = 0.0; p->refine_iters = 10; p->min_inliers = 4; p->stop_inliers = 0;
 }
 
 int mslam_fmat_ransac8_batch_dev(mslam_ctx* ctx, const double* x1, const double* x2, const int32_t* M, int capM,
@@ -2043,7 +2045,7 @@ int mslam_fmat_ransac8_batch_dev(mslam_ctx* ctx, const double* x1, const double*
         a.h_lo = lo; a.h_hi = hi;
         LAUNCH(ctx, K_FMAT_SOLVE, fmat_solve_k, dim3((hi - lo + 63) / 64, B), dim3(64), 0, a);
         LAUNCH(ctx, K_FMAT_SCORE, fmat_score_k, dim3((hi - lo + FM_HPB - 1) / FM_HPB, B), dim3(SCORE_THREADS), 0, a);
-        LAUNCH(ctx, K_RANSAC_SELECT, ransac_select_k, dim3(B), dim3(64), 0, a.counts, M, H, 8, prm->confidence, best_h, (int32_t*)nullptr, lo, hi, a.state, 1);
+        LAUNCH(ctx, K_RANSAC_SELECT, ransac_select_k, dim3(B), dim3(64), 0, a.counts, M, H, 8, prm->confidence, best_h, (int32_t*)nullptr, lo, hi, a.state, 1, 0);
         lo = hi;
     }
     LAUNCH(ctx, K_FMAT_FINALIZE, fmat_finalize_k, dim3(B), dim3(256), 0, a);
@@ -2136,7 +2138,7 @@ int mslam_fmat_ransac7_batch_dev(mslam_ctx* ctx, const double* x1, const double*
         LAUNCH(ctx, K_FMAT7_SOLVE, fmat7_solve_k, dim3((hi - lo + 63) / 64, B), dim3(64), 0, a);
         LAUNCH(ctx, K_FMAT_SCORE, fmat_score_k, dim3((3 * (hi - lo) + FM_HPB - 1) / FM_HPB, B), dim3(SCORE_THREADS), 0, a);
         LAUNCH(ctx, K_RANSAC_SELECT, ransac_select_k, dim3(B), dim3(64), 0, a.counts, M, HM, 7, prm->confidence, best_model, (int32_t*)nullptr,
-               3 * lo, 3 * hi, a.state, 3);
+               3 * lo, 3 * hi, a.state, 3, 0);
         lo = hi;
     }
     a.h_lo = 0; a.h_hi = HM;
@@ -2214,7 +2216,7 @@ int mslam_pnp_ransac_batch_dev(mslam_ctx* ctx, const double* X, const double* x,
     // each of the two scoring kernels leaves at once the problems the other one owns (distortion or not is device data)
     if (a.f32_tier) LAUNCH(ctx, K_PNP_SCORE32, pnp_score32_k, dim3((H + PNP_HPB - 1) / PNP_HPB, B), dim3(SCORE_THREADS), 0, a);
     LAUNCH(ctx, K_PNP_SCORE, pnp_score_k, dim3((H + PNP_HPB - 1) / PNP_HPB, B), dim3(SCORE_THREADS), 0, a);
-    LAUNCH(ctx, K_RANSAC_SELECT, ransac_select_k, dim3(B), dim3(64), 0, a.counts, P, H, 4, prm->confidence, best_h, a.best_cnt, 0, H, (int32_t*)nullptr, 1);
+    LAUNCH(ctx, K_RANSAC_SELECT, ransac_select_k, dim3(B), dim3(64), 0, a.counts, P, H, 4, prm->confidence, best_h, a.best_cnt, 0, H, (int32_t*)nullptr, 1, prm->stop_inliers);
     LAUNCH(ctx, K_PNP_FINALIZE, pnp_finalize_k, dim3(B), dim3(FIN_THREADS), 0, a);
     HIP_TRY(ctx, hipGetLastError());
     return MSLAM_OK;

@@ -34,6 +34,7 @@ CameraPoseEstimator::CameraPoseEstimator() : ProcessingNode("CameraPoseEstimator
     mslam_fmat_default_params(&fmat);
     fmat.threshold = MAX_DISTANCE; fmat.confidence = CONFIDENCE;
     mslam_pnp_default_params(&pnp);
+    pnp.stop_inliers = 100;   // solvePnPRansac's default minInliersCount: the call at :472 passes none, so its iterations end at the first pose with 100 inliers
     const double d[8] = { 0.2624, -0.9531, -0.0054, 0.0026, 1.1633, 0, 0, 0 };
     std::memcpy(distCoeff, d, sizeof(d));
 }

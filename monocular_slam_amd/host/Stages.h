@@ -46,7 +46,7 @@ public:
     // 7: OpenCV's own estimator behind findFundamentalMat(CV_FM_RANSAC) at :563 (mslam_fmat_ransac7: 7-point samples with up to
     //    three matrices each, runLMeDS below 15 matches, the direct solution for exactly 7)
     int fmatSamplePoints = 8;
-    mslam_pnp_params pnp;                           // 8 px (OpenCV 2.4 solvePnPRansac default)
+    mslam_pnp_params pnp;                           // 8 px, stop_inliers = 100 (OpenCV 2.4 solvePnPRansac defaults: reprojectionError, minInliersCount)
     int pnpHypotheses = 100;                        // OpenCV 2.4 default iterationsCount
     double distCoeff[8];                            // TUM freiburg1 coefficients hard-coded by the reference (:462-469)
     int numBackTraverse = 5;                        // (:388)

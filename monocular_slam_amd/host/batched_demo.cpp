@@ -1,7 +1,7 @@
 // batched_demo -- BatchedPipeline over S raw-frame sequences (the pipeline_demo input format, one file per stream), next to
 // what pipeline_demo gives for each of them alone.  Output: per stream "stream s", then the pipeline_demo lines
 // ("frame i nfeat r00 .. r23", "mappoints M", "id x y z nobs").
-//   batched_demo out.txt in0.bin in1.bin ... [--fmat7] [--nfeatures N] [--no-dist] [--pnp-hyps H] [--pnp-thr T] [--check-descriptors]
+//   batched_demo out.txt in0.bin in1.bin ... [--fmat7] [--pnp-stop N] [--nfeatures N] [--no-dist] [--pnp-hyps H] [--pnp-thr T] [--check-descriptors]
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
@@ -15,7 +15,7 @@ int main(int argc, char** argv)
     if (argc < 3) { std::fprintf(stderr, "usage: %s out.txt in0.bin [in1.bin ...] [--nfeatures N] [--no-dist] [--pnp-hyps H] [--pnp-thr T] [--check-descriptors] [--replicate R] [--time]\n", argv[0]); return 2; }
     std::vector<const char*> inputs;
     bool nodist = false, checkDesc = false, timeit = false;
-    int fmatPts = 8;
+    int fmatPts = 8, pnpStop = -1;
     int nfeatures = 500, pnpH = 100, replicate = 1;
     double pnpThr = 8.0;
     for (int i = 2; i < argc; i++) {
@@ -23,6 +23,7 @@ int main(int argc, char** argv)
         else if (!std::strcmp(argv[i], "--check-descriptors")) checkDesc = true;
         else if (!std::strcmp(argv[i], "--time")) timeit = true;
         else if (!std::strcmp(argv[i], "--replicate") && i + 1 < argc) replicate = std::atoi(argv[++i]);
+        else if (!std::strcmp(argv[i], "--pnp-stop") && i + 1 < argc) pnpStop = std::atoi(argv[++i]);   // minInliersCount (0: off)
         else if (!std::strcmp(argv[i], "--fmat7")) fmatPts = 7;   // OpenCV's 7-point estimator (the reference's live findFundamentalMat call)
         else if (!std::strcmp(argv[i], "--nfeatures") && i + 1 < argc) nfeatures = std::atoi(argv[++i]);
         else if (!std::strcmp(argv[i], "--pnp-hyps") && i + 1 < argc) pnpH = std::atoi(argv[++i]);
@@ -67,7 +68,7 @@ int main(int argc, char** argv)
         FeatureExtractor fe;
         fe.params.nfeatures = nfeatures;
         CameraPoseEstimator cpe;
-        cpe.pnpHypotheses = pnpH; cpe.pnp.reproj_thr = pnpThr; cpe.fmatSamplePoints = fmatPts;
+        cpe.pnpHypotheses = pnpH; cpe.pnp.reproj_thr = pnpThr; cpe.fmatSamplePoints = fmatPts; if (pnpStop >= 0) cpe.pnp.stop_inliers = pnpStop;
         if (nodist) for (double& d : cpe.distCoeff) d = 0.0;
         BatchedPipeline slam(dms, fe, cpe);
         std::vector<double> tick_ms;

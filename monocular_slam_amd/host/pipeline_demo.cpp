@@ -13,9 +13,9 @@
 
 int main(int argc, char** argv)
 {
-    if (argc < 3) { std::fprintf(stderr, "usage: %s in.bin out.txt [--ba] [--ba-window K] [--fmat7] [--nfeatures N] [--no-dist] [--pnp-hyps H] [--pnp-thr T]\n", argv[0]); return 2; }
+    if (argc < 3) { std::fprintf(stderr, "usage: %s in.bin out.txt [--ba] [--ba-window K] [--fmat7] [--pnp-stop N] [--nfeatures N] [--no-dist] [--pnp-hyps H] [--pnp-thr T]\n", argv[0]); return 2; }
     bool ba = false, nodist = false, twinCheck = false;
-    int fmatPts = 8;
+    int fmatPts = 8, pnpStop = -1;
     int nfeatures = 500, pnpH = 100, baWindow = 0;
     double pnpThr = 8.0;
     for (int i = 3; i < argc; i++) {
@@ -23,6 +23,7 @@ int main(int argc, char** argv)
         else if (!std::strcmp(argv[i], "--no-dist")) nodist = true;
         else if (!std::strcmp(argv[i], "--twin-check")) twinCheck = true;
         else if (!std::strcmp(argv[i], "--ba-window") && i + 1 < argc) { ba = true; baWindow = std::atoi(argv[++i]); }
+        else if (!std::strcmp(argv[i], "--pnp-stop") && i + 1 < argc) pnpStop = std::atoi(argv[++i]);   // minInliersCount (0: off)
         else if (!std::strcmp(argv[i], "--fmat7")) fmatPts = 7;   // OpenCV's 7-point estimator (the reference's live findFundamentalMat call)
         else if (!std::strcmp(argv[i], "--nfeatures") && i + 1 < argc) nfeatures = std::atoi(argv[++i]);
         else if (!std::strcmp(argv[i], "--pnp-hyps") && i + 1 < argc) pnpH = std::atoi(argv[++i]);
@@ -81,7 +82,7 @@ int main(int argc, char** argv)
         FeatureExtractor* fe = new FeatureExtractor();
         fe->params.nfeatures = nfeatures;
         CameraPoseEstimator* cpe = new CameraPoseEstimator();
-        cpe->pnpHypotheses = pnpH; cpe->pnp.reproj_thr = pnpThr; cpe->fmatSamplePoints = fmatPts;
+        cpe->pnpHypotheses = pnpH; cpe->pnp.reproj_thr = pnpThr; cpe->fmatSamplePoints = fmatPts; if (pnpStop >= 0) cpe->pnp.stop_inliers = pnpStop;
         if (nodist) for (double& d : cpe->distCoeff) d = 0.0;
         slam.addStage(fe);
         slam.addStage(cpe);

@@ -36,7 +36,7 @@ class FmatParams(C.Structure):
 
 class PnpParams(C.Structure):
     _fields_ = [("reproj_thr", C.c_double), ("confidence", C.c_double), ("refine_iters", C.c_int),
-                ("min_inliers", C.c_int)]
+                ("min_inliers", C.c_int), ("stop_inliers", C.c_int)]
 
 
 class BaProblem(C.Structure):

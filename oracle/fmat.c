@@ -192,6 +192,13 @@ static int ransac_update_iters(double p, double ep, int model_points, int max_it
  * bound shrinks with the inlier ratio.  confidence outside (0,1) disables the bound. */
 int orc_ransac_select(const int32_t* counts, int H, int n_points, int sample_size, double confidence, int* best_count)
 {
+    return orc_ransac_select_stop(counts, H, n_points, sample_size, confidence, 0, best_count);
+}
+
+/* ... with solvePnPRansac's early exit (OpenCV 2.4.13 PnPSolver::operator(): the loop over the iterations ends as soon as the best
+ * inlier set holds at least minInliersCount points): stop_count <= 0 switches it off */
+int orc_ransac_select_stop(const int32_t* counts, int H, int n_points, int sample_size, double confidence, int stop_count, int* best_count)
+{
     int niters = H, best = -1, maxgood = 0;
     int adaptive = confidence > 0. && confidence < 1.;
     for (int it = 0; it < niters; it++) {
@@ -200,6 +207,7 @@ int orc_ransac_select(const int32_t* counts, int H, int n_points, int sample_siz
         if (good > floor_) {
             best = it; maxgood = good;
             if (adaptive) niters = ransac_update_iters(confidence, (double)(n_points - good) / n_points, sample_size, niters);
+            if (stop_count > 0 && maxgood >= stop_count) break;
         }
     }
     if (best_count) *best_count = maxgood;

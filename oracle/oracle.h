@@ -95,6 +95,7 @@ int orc_fmat_ransac7(const double* x1, const double* x2, int M, const int32_t* s
                      int* best_model, int* n_inliers);
 /* adaptive-stop emulation shared by F and PnP: returns winning hypothesis over ordered counts */
 int orc_ransac_select(const int32_t* counts, int H, int n_points, int sample_size, double confidence, int* best_count);
+int orc_ransac_select_stop(const int32_t* counts, int H, int n_points, int sample_size, double confidence, int stop_count, int* best_count);
 
 /* ---------------- pose from F, triangulation (reference :86-194, :248-255, :316-356) */
 int orc_triangulate(const double* x1, const double* x2, int n, const double Rt1[12], const double Rt2[12],
@@ -104,7 +105,7 @@ int orc_pose_from_F(const double F[9], const double K1[9], const double K2[9], c
                     int n, double Rt[12], double* X, int* counts4);
 
 /* ---------------- PnP (solvePnPRansac contract; reference src/CameraPoseEstimator.cpp:462-474) */
-typedef struct { double reproj_thr; double confidence; int refine_iters; int min_inliers; } orc_pnp_params;
+typedef struct { double reproj_thr; double confidence; int refine_iters; int min_inliers; int stop_inliers; } orc_pnp_params;
 void orc_pnp_default_params(orc_pnp_params* p);
 /* P3P: up to 4 poses (R row-major 3x3, t) from 3 unit bearings f and 3 world points X; returns count */
 int orc_p3p(const double f[9], const double X[9], double R[4][9], double t[4][3]);

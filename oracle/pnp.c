@@ -37,7 +37,7 @@
 
 void orc_pnp_default_params(orc_pnp_params* p)
 {
-    p->reproj_thr = 8.0; p->confidence = 0.0; p->refine_iters = 10; p->min_inliers = 4;
+    p->reproj_thr = 8.0; p->confidence = 0.0; p->refine_iters = 10; p->min_inliers = 4; p->stop_inliers = 0;
 }
 
 /* iterative inverse of the distortion model (cvUndistortPoints' fixed-point iteration, 10 rounds) */
@@ -426,7 +426,7 @@ int orc_pnp_ransac(const double* X, const double* x, int P, const double K[9], c
         counts[h] = orc_pnp_hypothesis(X, xn, x, K, dist, samples + 4 * h, hyp) ? pnp_count(X, x, P, K, dist, hyp, prm->reproj_thr, NULL) : 0;
     }
     int bc = 0;
-    int best = orc_ransac_select(counts, H, P, 4, prm->confidence, &bc);
+    int best = orc_ransac_select_stop(counts, H, P, 4, prm->confidence, prm->stop_inliers, &bc);
     if (!inlier_counts) free(counts);
     int rc = 0;
     if (best < 0 || bc < prm->min_inliers) rc = -6;

@@ -109,6 +109,18 @@ def main():
     ofa = ob.fmat_default_params()
     tca = cpu_time(lambda: ob.fmat_ransac8(tvs[0]["x1"], tvs[0]["x2"], S8, ofa))
     out["F eight-point RANSAC 2000x4096, confidence 0.85 without counts (GPU stops at the adaptive bound; the oracle scores every hypothesis, then selects)"] = dict(unit="problems/s", gpu=B / t, cpu=1 / tca, alg_bytes=32 * M + 72 + M)
+    # ---- the 7-point estimator (findFundamentalMat(CV_FM_RANSAC) as OpenCV runs it): H samples, up to three matrices each
+    S7 = synth.sample_table(M, Hh, 7, 7)
+    S7s = np.stack([(S7 + 5 * i) % M for i in range(B)]).astype(np.int32)
+    f7 = dict(S=D(ctx, S7s), cnt=api.DevBuf(ctx, B * Hh * 3 * 4))
+    t = gpu_time(ctx, lambda: ctx.fmat_ransac7_batch_dev(fb["x1"].ptr, fb["x2"].ptr, fb["M"].ptr, M, f7["S"].ptr, Hh, B, fp, 0, fb["F"].ptr,
+                                                         fb["st"].ptr, f7["cnt"].ptr, fb["best"].ptr, fb["ninl"].ptr), tag='fmat7')
+    tc = cpu_time(lambda: ob.fmat_ransac7(tvs[0]["x1"], tvs[0]["x2"], S7, ofp))
+    out["F seven-point RANSAC 2000x4096 (up to 3 matrices per sample)"] = dict(unit="problems/s", gpu=B / t, cpu=1 / tc, alg_bytes=32 * M + 28 * Hh + 72 + M + 12 * Hh)
+    t = gpu_time(ctx, lambda: ctx.fmat_ransac7_batch_dev(fb["x1"].ptr, fb["x2"].ptr, fb["M"].ptr, M, f7["S"].ptr, Hh, B, fpa, 0, fb["F"].ptr,
+                                                         fb["st"].ptr, 0, fb["best"].ptr, fb["ninl"].ptr), tag='fmat7_adaptive')
+    tca = cpu_time(lambda: ob.fmat_ransac7(tvs[0]["x1"], tvs[0]["x2"], S7, ofa))
+    out["F seven-point RANSAC 2000x4096, confidence 0.85 without counts (as the stages call it with fmatSamplePoints = 7)"] = dict(unit="problems/s", gpu=B / t, cpu=1 / tca, alg_bytes=32 * M + 72 + M)
     # ---- C3 BA build
     pr = synth.ba_problem(10, 5000, 4004)
     plan = api.BaPlan(ctx, pr)

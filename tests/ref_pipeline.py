@@ -69,7 +69,7 @@ def fundamental(ob, p1, p2, qi, ti, seed, H=2000, k=8):
     return r["F"], r["status"], a, b
 
 
-def run(ob, frames, K, nfeatures=500, seed=5, pnp_hyps=100, pnp_thr=8.0, dist=None, fmat_points=8):   # seed = CameraPoseEstimator::seed's default (Stages.h)
+def run(ob, frames, K, nfeatures=500, seed=5, pnp_hyps=100, pnp_thr=8.0, dist=None, fmat_points=8, pnp_stop=100):   # seed = CameraPoseEstimator::seed's default (Stages.h)
     """Returns per-frame dict(kps, desc, Rt, map_idx) and the map (positions, observers)."""
     p = ob.orb_default_params(nfeatures)
     dist = np.zeros(8) if dist is None else dist
@@ -118,6 +118,7 @@ def run(ob, frames, K, nfeatures=500, seed=5, pnp_hyps=100, pnp_thr=8.0, dist=No
         f["Rt"] = F[i - 1]["Rt"].copy()
         if len(Xs) >= 4:
             pp = ob.pnp_default_params(); pp.reproj_thr = pnp_thr
+            pp.stop_inliers = pnp_stop   # the stage's default: solvePnPRansac's minInliersCount (100)
             r = ob.pnp_ransac(np.array(Xs), np.array(xs), K, dist, sample_table(len(Xs), pnp_hyps, 4, seed + 1000 * i + 99), pp)
             if r["rc"] == 0:
                 f["Rt"] = r["Rt"]

@@ -493,3 +493,23 @@ def test_fmat_ransac7_batch_mixes_estimators(ctx, oracle):
         np.testing.assert_array_equal(st[b, :m], o["status"])
         np.testing.assert_array_equal(cnt[b], o["counts"])
         _close(F[b], o["F"], 1e-7)
+
+
+@pytest.mark.parametrize("stop", [0, 50, 100, 250, 10 ** 6])
+def test_pnp_early_exit_at_min_inliers_count(ctx, oracle, stop):
+    """mslam_pnp_params.stop_inliers = OpenCV 2.4's minInliersCount: the scan ends at the first hypothesis with that many inliers."""
+    pr = synth.pnp_problem(400, 77)
+    S = synth.sample_table(400, 300, 4, 78)
+    p = api.default_pnp_params()
+    p.reproj_thr, p.stop_inliers = 3.0, stop
+    g = ctx.pnp_ransac(pr["X"], pr["x"], pr["K"], pr["dist"], S, p)
+    o = oracle.pnp_ransac(pr["X"], pr["x"], pr["K"], pr["dist"], S, _pp(oracle, p))
+    assert g["rc"] == o["rc"] == 0 and g["best_h"] == o["best_h"] and g["n_inliers"] == o["n_inliers"]
+    np.testing.assert_array_equal(g["counts"], o["counts"])
+    np.testing.assert_array_equal(g["inliers"], o["inliers"])
+    c = g["counts"]
+    if 0 < stop <= c.max():
+        first = int(np.argmax(c >= stop))
+        assert g["best_h"] == first and c[:first].max(initial=0) < stop      # the first one that reaches it, not the best one
+    else:
+        assert g["best_h"] == int(np.argmax(c))
