@@ -1086,6 +1086,20 @@ __device__ __forceinline__ void blur_rows(const uint32_t* __restrict__ raw32, ui
     }
 }
 
+// Sum of an int over the wavefront, returned in a scalar register: an inclusive scan inside each row of 16 lanes by DPP row shifts
+// (1, 2, 4, 8; zeros shifted in), row totals passed on by row_bcast:15 / row_bcast:31, the total read from lane 63.  Six vector
+// additions with DPP operands and no LDS round trip (a butterfly of __shfl_xor is six dependent ds_bpermute latencies).
+__device__ __forceinline__ int wave_sum_dpp(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);   // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);   // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);   // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);   // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2 and 3
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
 struct DescArgs {
     mslam_keypoint* kps; uint8_t* desc; int32_t* n_out; int32_t* status; int cap;
 };
@@ -1163,8 +1177,7 @@ void describe_k(OrbDev od, DescArgs out)
         m10 = (int)sx - 15 * (int)rs;
         m01 = __mul24(v, (int)rs);
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { m10 += __shfl_xor(m10, o); m01 += __shfl_xor(m01, o); }
+    m10 = wave_sum_dpp(m10); m01 = wave_sum_dpp(m01);
     const float angle = fast_atan2_deg((float)m01, (float)m10);
     // ---- 7x7 Gaussian of the patch with packed dot products (integer arithmetic: any association is exact).
     // Rows: one item = 2 patch rows x 4 output columns by v_dot4_u32_u8 (blur_rows, one instantiation per byte alignment of the
