@@ -808,19 +808,42 @@ __device__ __forceinline__ uint32_t float_key(float f)
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u); // order-preserving
 }
 
+// Wavefront reductions and scans by DPP operands -- no LDS round trips (a butterfly of __shfl_xor is six dependent ds_bpermute
+// latencies, with four vector instructions of address arithmetic each).  An inclusive scan inside each row of 16 lanes by row shifts
+// (1, 2, 4, 8), then the row totals passed on by row_bcast:15 (into rows 1, 3) and row_bcast:31 (into rows 2, 3): lane l holds
+// the result over lanes 0..l, lane 63 the result over the wavefront.
+__device__ __forceinline__ int wave_scan_add_dpp(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);   // row_shr:1 (zeros shifted in)
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);   // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);   // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);   // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast:15
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);  // row_bcast:31
+    return v;
+}
+__device__ __forceinline__ int wave_sum_dpp(int v) { return __builtin_amdgcn_readlane(wave_scan_add_dpp(v), 63); }   // -> scalar register
+// (max / min: a lane without a source keeps its own value)
+#define MSLAM_DPP_FOLD(OP, v)                                                              \
+    v = OP(v, __builtin_amdgcn_update_dpp(v, v, 0x111, 0xf, 0xf, false));                  \
+    v = OP(v, __builtin_amdgcn_update_dpp(v, v, 0x112, 0xf, 0xf, false));                  \
+    v = OP(v, __builtin_amdgcn_update_dpp(v, v, 0x114, 0xf, 0xf, false));                  \
+    v = OP(v, __builtin_amdgcn_update_dpp(v, v, 0x118, 0xf, 0xf, false));                  \
+    v = OP(v, __builtin_amdgcn_update_dpp(v, v, 0x142, 0xa, 0xf, false));                  \
+    v = OP(v, __builtin_amdgcn_update_dpp(v, v, 0x143, 0xc, 0xf, false));
+__device__ __forceinline__ int wave_max_dpp(int v) { MSLAM_DPP_FOLD(max, v) return __builtin_amdgcn_readlane(v, 63); }
+__device__ __forceinline__ int wave_min_dpp(int v) { MSLAM_DPP_FOLD(min, v) return __builtin_amdgcn_readlane(v, 63); }
+
 // Suffix sums of the 256-bin histogram by the first wavefront (lane l owns bins 4 l .. 4 l + 3): inc[q] = number of entries in
 // bins >= 4 l + q.  Replaces a scan by one thread, whose 256 dependent LDS reads were the longest step of select_k.
 __device__ __forceinline__ void hist_suffix(const uint32_t* s_hist, int lane, uint32_t (&h)[4], uint32_t (&inc)[4])
 {
     const uint4 hv = *reinterpret_cast<const uint4*>(s_hist + 4 * lane);
     h[0] = hv.x; h[1] = hv.y; h[2] = hv.z; h[3] = hv.w;
-    uint32_t sfx = h[0] + h[1] + h[2] + h[3];
-    const uint32_t own = sfx;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t t = __shfl_down(sfx, off);
-        if (lane + off < 64) sfx += t;
-    }
+    const uint32_t own = h[0] + h[1] + h[2] + h[3];
+    // suffix over the lanes from the prefix scan: sum(l..63) = total - sum(0..l) + own
+    const uint32_t pre = (uint32_t)wave_scan_add_dpp((int)own);
+    const uint32_t sfx = (uint32_t)__builtin_amdgcn_readlane((int)pre, 63) - pre + own;
     inc[3] = sfx - own + h[3]; inc[2] = inc[3] + h[2]; inc[1] = inc[2] + h[1]; inc[0] = inc[1] + h[0];
 }
 
@@ -834,9 +857,7 @@ __device__ __forceinline__ void radix_step(const uint32_t* s_hist, int lane, int
     int bl = 0;
 #pragma unroll
     for (int q = 0; q < 4; q++) if ((int)inc[q] >= k && 4 * lane + q >= 1) bl = 4 * lane + q;
-    int bin = bl;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) bin = max(bin, __shfl_xor(bin, off));
+    const int bin = wave_max_dpp(bl);
     if (lane == (bin >> 2)) {
         *s_k = k - (int)(inc[bin & 3] - h[bin & 3]);
         *s_prefix = prefix | ((uint32_t)bin << shift); *s_mask = mask | (255u << shift);
@@ -883,9 +904,7 @@ void select_k(OrbDev od)
         int Tl = 256;
 #pragma unroll
         for (int q = 3; q >= 0; q--) if ((int)(inc[q] - h[q]) < n1) Tl = 4 * tid + q;   // (true for a range of bins that ends at 255)
-        int Tw = Tl;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) Tw = min(Tw, __shfl_xor(Tw, off));
+        const int Tw = wave_min_dpp(Tl);
         if (tid == 0) { s_T = Tw; if (Tw >= 256) s_nKeep = 0; }
         if (Tw < 256 && tid == (Tw >> 2)) s_nKeep = (int)inc[Tw & 3];   // candidates with score >= T
     }
@@ -1084,20 +1103,6 @@ __device__ __forceinline__ void blur_rows(const uint32_t* __restrict__ raw32, ui
 #pragma unroll
         for (int k = 0; k < 4; k++) hT[(4 * cg + k) * HT_DW + rp] = h[0][k] | (h[1][k] << 16);
     }
-}
-
-// Sum of an int over the wavefront, returned in a scalar register: an inclusive scan inside each row of 16 lanes by DPP row shifts
-// (1, 2, 4, 8; zeros shifted in), row totals passed on by row_bcast:15 / row_bcast:31, the total read from lane 63.  Six vector
-// additions with DPP operands and no LDS round trip (a butterfly of __shfl_xor is six dependent ds_bpermute latencies).
-__device__ __forceinline__ int wave_sum_dpp(int v)
-{
-    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);   // row_shr:1
-    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);   // row_shr:2
-    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);   // row_shr:4
-    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);   // row_shr:8
-    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
-    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2 and 3
-    return __builtin_amdgcn_readlane(v, 63);
 }
 
 struct DescArgs {
