@@ -919,7 +919,7 @@ void select_k(OrbDev od)
             unsigned long long bal = __ballot(keep);
             int base = 0;
             if ((tid & 63) == 0 && bal) base = atomicAdd(&s_nA, __popcll(bal));
-            base = __shfl(base, 0);
+            base = __builtin_amdgcn_readfirstlane(base);   // (every lane is active here: lane 0 holds the reservation)
             if (keep) surv[base + __popcll(bal & ((1ull << (tid & 63)) - 1ull))].x = c;
         };
 #pragma unroll
@@ -958,7 +958,7 @@ void select_k(OrbDev od)
             unsigned long long bal = __ballot(keep);
             int base = 0;
             if ((tid & 63) == 0 && bal) base = atomicAdd(&s_nS, __popcll(bal));
-            base = __shfl(base, 0);
+            base = __builtin_amdgcn_readfirstlane(base);   // (every lane is active here: lane 0 holds the reservation)
             int pos = base + __popcll(bal & ((1ull << (tid & 63)) - 1ull));
             __syncthreads();
             if (keep) surv[pos] = make_uint2(e.x & 0xFFFFFFu, e.y);
@@ -974,7 +974,7 @@ void select_k(OrbDev od)
             unsigned long long bal = __ballot(keep);
             int base = 0;
             if ((tid & 63) == 0 && bal) base = atomicAdd(&s_nA, __popcll(bal));
-            base = __shfl(base, 0);
+            base = __builtin_amdgcn_readfirstlane(base);   // (every lane is active here: lane 0 holds the reservation)
             if (keep) candA[base + __popcll(bal & ((1ull << (tid & 63)) - 1ull))] = c;
         }
         __syncthreads();
@@ -1011,7 +1011,7 @@ void select_k(OrbDev od)
             unsigned long long bal = __ballot(keep);
             int base = 0;
             if ((tid & 63) == 0 && bal) base = atomicAdd(&s_nS, __popcll(bal));
-            base = __shfl(base, 0);
+            base = __builtin_amdgcn_readfirstlane(base);   // (every lane is active here: lane 0 holds the reservation)
             int pos = base + __popcll(bal & ((1ull << (tid & 63)) - 1ull));
             if (keep && pos < od.max_kpts) surv[pos] = make_uint2(candA[i] & 0xFFFFFFu, __float_as_uint(r));
         }
