@@ -39,7 +39,7 @@
 
 namespace {
 
-__constant__ int8_t c_pattern[256 * 4] = {
+__constant__ __attribute__((aligned(16))) int8_t c_pattern[256 * 4] = {   // (read as one dword per test by describe_k)
 #include "orb_pattern_31.inc"
 };
 // u_max of IC_Angle for half patch 15 (OpenCV computeKeyPoints)
@@ -1153,6 +1153,15 @@ void describe_k(OrbDev od, DescArgs out)
     const int px0 = x - DP_R, py0 = y - DP_R;
     const int xa = px0 & ~3, xo = px0 & 3;
     uint32_t* raw32 = s_raw[wave];
+    // The lane's constant-table entries -- IC-angle weights of its half row, pattern points of its four tests -- are fetched here, so
+    // that their latency passes under the patch staging: read where they are used they sit behind the barriers (a load is not moved
+    // across one), one exposed memory latency each.
+    const int icv = (min(lane, 61) >> 1) - 15;
+    const uint4* wt = reinterpret_cast<const uint4*>(c_icw[abs(icv) * 2 + (lane & 1)]);
+    const uint4 wx = wt[0], wm = wt[1];
+    uint32_t pat[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) pat[j] = reinterpret_cast<const uint32_t*>(c_pattern)[j * 64 + lane];
     {
         constexpr int NCH = DP_N * (DP_PITCH / 16);
         const uint8_t* g0 = img + (size_t)py0 * lv.pitch + xa;
@@ -1175,8 +1184,6 @@ void describe_k(OrbDev od, DescArgs out)
         const uint32_t d0 = q[0], d1 = q[1], d2 = q[2], d3 = q[3], d4 = q[4];
         const uint32_t e0 = __builtin_amdgcn_alignbyte(d1, d0, sh), e1 = __builtin_amdgcn_alignbyte(d2, d1, sh),
                        e2 = __builtin_amdgcn_alignbyte(d3, d2, sh), e3 = __builtin_amdgcn_alignbyte(d4, d3, sh);
-        const uint4* wt = reinterpret_cast<const uint4*>(c_icw[abs(v) * 2 + half]);
-        const uint4 wx = wt[0], wm = wt[1];
         const uint32_t sx = __builtin_amdgcn_udot4(e3, wx.w, __builtin_amdgcn_udot4(e2, wx.z, __builtin_amdgcn_udot4(e1, wx.y, __builtin_amdgcn_udot4(e0, wx.x, 0u, false), false), false), false);
         const uint32_t rs = __builtin_amdgcn_udot4(e3, wm.w, __builtin_amdgcn_udot4(e2, wm.z, __builtin_amdgcn_udot4(e1, wm.y, __builtin_amdgcn_udot4(e0, wm.x, 0u, false), false), false), false);
         m10 = (int)sx - 15 * (int)rs;
@@ -1226,7 +1233,7 @@ void describe_k(OrbDev od, DescArgs out)
     unsigned long long bits[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-        const int8_t* pt = c_pattern + (j * 64 + lane) * 4;
+        const int8_t pt[4] = { (int8_t)(pat[j] & 255u), (int8_t)((pat[j] >> 8) & 255u), (int8_t)((pat[j] >> 16) & 255u), (int8_t)(pat[j] >> 24) };
         float x0 = pt[0] * ca - pt[1] * sb, y0 = pt[0] * sb + pt[1] * ca;
         float x1 = pt[2] * ca - pt[3] * sb, y1 = pt[2] * sb + pt[3] * ca;
         const int t0 = blurred(__float2int_rn(x0), __float2int_rn(y0));
