@@ -811,7 +811,9 @@ __device__ __forceinline__ uint32_t float_key(float f)
 // Wavefront reductions and scans by DPP operands -- no LDS round trips (a butterfly of __shfl_xor is six dependent ds_bpermute
 // latencies, with four vector instructions of address arithmetic each).  An inclusive scan inside each row of 16 lanes by row shifts
 // (1, 2, 4, 8), then the row totals passed on by row_bcast:15 (into rows 1, 3) and row_bcast:31 (into rows 2, 3): lane l holds
-// the result over lanes 0..l, lane 63 the result over the wavefront.
+// the result over lanes 0..l, lane 63 the result over the wavefront.  Every lane of the wavefront must be active at the call (an
+// inactive lane feeds its neighbours stale register contents): the callers are whole wavefronts (select_k under `tid < 64`,
+// describe_k outside any lane-dependent branch).
 __device__ __forceinline__ int wave_scan_add_dpp(int v)
 {
     v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);   // row_shr:1 (zeros shifted in)
