@@ -363,7 +363,10 @@ void mslam_ba_plan_destroy(mslam_ba_plan* plan);
 /* device views of the plan's state and of the system it builds (all device pointers) */
 typedef struct {
     double* poses; double* points;         /* state: n_poses x 7, n_points x 3 */
-    double* err; double* chi2; double* rho1;
+    double* err; double* chi2; double* rho1;  /* err, chi2: per edge, in the plan's ROW ORDER (edges sorted by pose row, then point:
+                                              the order of the Hpl blocks); rho1: NULL -- the Huber weight is a function of chi2
+                                              and is not streamed out; mslam_ba_plan_download returns all three in the caller's
+                                              edge order */
     double* Hpp; double* Hll; double* Hpl_val; double* b;
     int32_t* Hpl_rowptr; int32_t* Hpl_col;
     double* robust_chi2;                   /* 1 double */

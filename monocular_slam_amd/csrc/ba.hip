@@ -17,7 +17,7 @@
 //   state    poses f64[n_poses][7] (t, q xyzw), points f64[n_points][3]
 //   rows     erowptr i32[R+1], row_pose i32[R]; rec i32x2[E] (point, original edge id), obs_k f64x2[E]
 //   by point pt_ptr i32[n_points+1], pt_k i32[E]   (row-order indices of a point's edges, ascending)
-//   ptside   f64[10][E]   per-edge point-side contributions (6 Hll + 3 b_l + rho), plane-major: coalesced both ways
+//   ptside   f64[9][E]    per-edge point-side contributions (6 Hll + 3 b_l), plane-major: coalesced both ways
 // Kernels of one linearisation (no float atomics anywhere: every sum has a fixed shape, results are run-to-run identical):
 //   ba_edges_k   grid (chunk, row), one lane per edge: residual, Huber weight, Jacobians ONCE per edge; err/chi2/rho1 by
 //                edge id; the point-side terms into ptside; for free rows the 6x3 block goes through an LDS transpose and
@@ -57,7 +57,7 @@ struct BaDev {
     int n_poses, n_points, n_edges, n_free, nnzb, n_rows, n_chunks_max;
     double huber_delta; float dsqr;
     const double* poses; const double* points;
-    const int32_t* edge_pose; const double* info; const double* intr;
+    const int32_t* edge_pose; const double* info /* [E] in ROW order */; const double* intr;
     const int32_t* fidx;      // free index per pose or -1
     const int32_t* erowptr; const int32_t* row_pose;
     const int2* rec;          // [E] {point, edge id} in row order
@@ -65,7 +65,7 @@ struct BaDev {
     const int32_t* pt_ptr; const int32_t* pt_k;
     const int32_t* blk_row;   // [nnzb] free row of a block
     double* err; double* chi2; double* rho1; double* Hpp; double* Hll; double* Hpl_val; double* b;
-    double* ptside;           // [10][E]
+    double* ptside;           // [9][E]
     double* pt_rho;           // [n_points] robust chi2 per point
     double* chi_part;         // [ceil(n_points / 4096)] slice sums of pt_rho (large problems)
     double* pose_part;        // [n_free][n_chunks_max][27]
@@ -182,15 +182,15 @@ void ba_edges_k(BaDev d)
     if (live) {
         const int2 rc = d.rec[k];
         const double2 ob = d.obs_k[k];
-        const int ip = rc.x, e = rc.y;
+        const int ip = rc.x;   // (rc.y, the caller's edge id, is only needed by the host: mslam_ba_plan_download)
         const double* in = d.intr + 4 * jp;
         EdgeLin L;
         edge_eval(d.poses + 7 * jp, d.points[3 * ip], d.points[3 * ip + 1], d.points[3 * ip + 2], ob.x, ob.y, in[0], in[1], in[2], in[3], L);
-        const double om = d.info[e];
+        const double om = d.info[k];   // (row order, like every other per-edge stream of this kernel: no scattered 8-byte accesses)
         const double chi2 = L.e0 * (om * L.e0) + L.e1 * (om * L.e1);
         double rho0, rho1;
         huber(chi2, d.huber_delta, d.dsqr, rho0, rho1);
-        d.err[2 * e] = L.e0; d.err[2 * e + 1] = L.e1; d.chi2[e] = chi2; d.rho1[e] = rho1;
+        reinterpret_cast<double2*>(d.err)[k] = make_double2(L.e0, L.e1); d.chi2[k] = chi2;   // row order; mslam_ba_plan_download permutes (and forms rho1 from chi2)
         const double wom = rho1 * om;
         const double r0 = -(om * L.e0) * rho1, r1 = -(om * L.e1) * rho1;
         const double* A = L.A;
@@ -200,7 +200,7 @@ void ba_edges_k(BaDev d)
         ps[2 * E] = wom * (A[0] * A[2] + A[3] * A[5]); ps[3 * E] = wom * (A[1] * A[1] + A[4] * A[4]);
         ps[4 * E] = wom * (A[1] * A[2] + A[4] * A[5]); ps[5 * E] = wom * (A[2] * A[2] + A[5] * A[5]);
         ps[6 * E] = A[0] * r0 + A[3] * r1; ps[7 * E] = A[1] * r0 + A[4] * r1; ps[8 * E] = A[2] * r0 + A[5] * r1;
-        ps[9 * E] = rho0;
+        (void)rho0;   // (the point's robust chi2 is re-formed from chi2 in ba_points_k: a tenth plane of 8 bytes per edge saved)
         if (f >= 0) {
 #pragma unroll
             for (int a = 0; a < 6; a++) { // B^T (w Omega) A, row-major 6x3
@@ -246,9 +246,13 @@ void ba_points_k(BaDev d)
     for (int q = 0; q < 10; q++) acc[q] = 0.0;
     const size_t E = (size_t)d.n_edges;
     for (int kk = d.pt_ptr[i]; kk < d.pt_ptr[i + 1]; kk++) {   // ascending row order: a fixed summation order
-        const double* ps = d.ptside + d.pt_k[kk];
+        const int k = d.pt_k[kk];
+        const double* ps = d.ptside + k;
 #pragma unroll
-        for (int q = 0; q < 10; q++) acc[q] += ps[q * E];
+        for (int q = 0; q < 9; q++) acc[q] += ps[q * E];
+        double rho0, rho1;   // the edge's robust chi2 from its chi2 (row order, as ba_edges_k left it): the same operations as there
+        huber(d.chi2[k], d.huber_delta, d.dsqr, rho0, rho1);
+        acc[9] += rho0;
     }
     double* H = d.Hll + (size_t)i * 9;
     H[0] = acc[0]; H[1] = acc[1]; H[2] = acc[2];
@@ -652,6 +656,8 @@ struct mslam_ba_plan {
     double* d_lam = nullptr;                 // [max(1, n_windows)]
     std::vector<int32_t> h_rowptr, h_col;
     std::vector<int32_t> h_row_pose;         // pose of a free row
+    double built_delta = 0.0; float built_dsqr = 0.f;   // robust kernel of the last build (rho1 is formed from chi2 at download)
+    std::vector<int32_t> h_edge_of_k;        // original edge id of row-order position k (err / chi2 / rho1 / info live in row order on the device)
     bool has_schur = false;
     int schur_lmax = 0;       // widest Schur tile (local poses): selects ba_schur_tiles_k's instantiation
 };
@@ -824,10 +830,10 @@ int mslam_ba_plan_create(mslam_ctx* ctx, const mslam_ba_problem* p, mslam_ba_pla
                  o_rec = reserve(sizeof(int2) * E), o_obs = reserve(sizeof(double2) * E),
                  o_ptp = reserve(sizeof(int32_t) * (NL + 1)), o_ptk = reserve(sizeof(int32_t) * E),
                  o_col = reserve(sizeof(int32_t) * std::max(nnzb, 1)), o_brow = reserve(sizeof(int32_t) * std::max(nnzb, 1)),
-                 o_err = reserve(sizeof(double) * 2 * E), o_chi = reserve(sizeof(double) * E), o_rho = reserve(sizeof(double) * E),
+                 o_err = reserve(sizeof(double) * 2 * E), o_chi = reserve(sizeof(double) * E),
                  o_hpp = reserve(sizeof(double) * 36 * std::max(nf, 1)), o_hll = reserve(sizeof(double) * 9 * NL),
                  o_hpl = reserve(sizeof(double) * 18 * std::max(nnzb, 1)), o_b = reserve(sizeof(double) * (6 * nf + 3 * NL)),
-                 o_pts = reserve(sizeof(double) * 10 * (size_t)E),
+                 o_pts = reserve(sizeof(double) * 9 * (size_t)E),
                  o_ptr = reserve(sizeof(double) * NL), o_chp = reserve(sizeof(double) * ((size_t)NL / CHI_SLICE + 1)),
                  o_pp = reserve(sizeof(double) * 27 * (size_t)std::max(nf, 1) * n_chunks_max), o_rc = reserve(sizeof(double)),
                  o_lam = reserve(sizeof(double));
@@ -853,9 +859,12 @@ int mslam_ba_plan_create(mslam_ctx* ctx, const mslam_ba_problem* p, mslam_ba_pla
     hipStream_t st = ctx->stream;
     auto up = [&](size_t off, const void* src, size_t n) { return n ? hipMemcpyAsync(base + off, src, n, hipMemcpyHostToDevice, st) : hipSuccess; };
     const double lam0 = 0.0;
+    std::vector<double> info_k(E);
+    pl->h_edge_of_k.resize(E);
+    for (int k = 0; k < E; k++) { pl->h_edge_of_k[(size_t)k] = rec[(size_t)k].y; info_k[(size_t)k] = p->info[rec[(size_t)k].y]; }
     std::vector<hipError_t> errs = {
         up(o_poses, p->poses, sizeof(double) * 7 * NP), up(o_points, p->points, sizeof(double) * 3 * NL),
-        up(o_ep, p->edge_pose, sizeof(int32_t) * E), up(o_info, p->info, sizeof(double) * E), up(o_intr, p->intr, sizeof(double) * 4 * NP),
+        up(o_ep, p->edge_pose, sizeof(int32_t) * E), up(o_info, info_k.data(), sizeof(double) * E), up(o_intr, p->intr, sizeof(double) * 4 * NP),
         up(o_fidx, fidx.data(), sizeof(int32_t) * NP), up(o_erow, erowptr.data(), sizeof(int32_t) * (R + 1)),
         up(o_rowp, row_pose.data(), sizeof(int32_t) * R), up(o_rec, rec.data(), sizeof(int2) * E), up(o_obs, obs_k.data(), sizeof(double2) * E),
         up(o_ptp, pt_ptr.data(), sizeof(int32_t) * (NL + 1)), up(o_ptk, pt_k.data(), sizeof(int32_t) * E),
@@ -882,7 +891,7 @@ int mslam_ba_plan_create(mslam_ctx* ctx, const mslam_ba_problem* p, mslam_ba_pla
     d.edge_pose = (int32_t*)(base + o_ep); d.info = (double*)(base + o_info); d.intr = (double*)(base + o_intr); d.fidx = (int32_t*)(base + o_fidx);
     d.erowptr = (int32_t*)(base + o_erow); d.row_pose = (int32_t*)(base + o_rowp); d.rec = (int2*)(base + o_rec); d.obs_k = (double2*)(base + o_obs);
     d.pt_ptr = (int32_t*)(base + o_ptp); d.pt_k = (int32_t*)(base + o_ptk); d.blk_row = (int32_t*)(base + o_brow);
-    d.err = (double*)(base + o_err); d.chi2 = (double*)(base + o_chi); d.rho1 = (double*)(base + o_rho);
+    d.err = (double*)(base + o_err); d.chi2 = (double*)(base + o_chi); d.rho1 = nullptr;   // (the Huber weight is a function of chi2: not streamed out per edge)
     d.Hpp = (double*)(base + o_hpp); d.Hll = (double*)(base + o_hll); d.Hpl_val = (double*)(base + o_hpl); d.b = (double*)(base + o_b);
     d.ptside = (double*)(base + o_pts);
     d.pt_rho = (double*)(base + o_ptr); d.chi_part = (double*)(base + o_chp); d.pose_part = (double*)(base + o_pp); d.robust_chi2 = (double*)(base + o_rc);
@@ -946,8 +955,10 @@ int mslam_ba_plan_set_robust(mslam_ba_plan* pl, const double* info, double huber
     if (!pl) return MSLAM_ERR_INVALID;
     mslam_ctx* ctx = pl->ctx;
     MSLAM_TRY(ctx_set_device(ctx));
-    if (info) {
-        HIP_TRY(ctx, hipMemcpyAsync(const_cast<double*>(pl->dev.info), info, sizeof(double) * pl->dev.n_edges, hipMemcpyHostToDevice, ctx->stream));
+    if (info) {   // the device copy is in row order
+        std::vector<double> info_k((size_t)pl->dev.n_edges);
+        for (int k = 0; k < pl->dev.n_edges; k++) info_k[(size_t)k] = info[pl->h_edge_of_k[(size_t)k]];
+        HIP_TRY(ctx, hipMemcpyAsync(const_cast<double*>(pl->dev.info), info_k.data(), sizeof(double) * pl->dev.n_edges, hipMemcpyHostToDevice, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     }
     pl->dev.huber_delta = huber_delta;
@@ -999,6 +1010,7 @@ int mslam_ba_plan_build_dev(mslam_ba_plan* pl)
     mslam_ctx* ctx = pl->ctx;
     MSLAM_TRY(ctx_set_device(ctx));
     const BaDev& d = pl->dev;
+    pl->built_delta = d.huber_delta; pl->built_dsqr = d.dsqr;
     LAUNCH(ctx, K_BA_POSES, ba_edges_k, dim3(d.n_chunks_max, d.n_rows), dim3(EDGE_CHUNK), 0, d);
     LAUNCH(ctx, K_BA_POINTS, ba_points_k, dim3((d.n_points + 255) / 256), dim3(256), 0, d);
     if (d.n_points <= 2 * CHI_SLICE && d.n_free * 27 <= 4096) {
@@ -1021,15 +1033,28 @@ int mslam_ba_plan_download(mslam_ba_plan* pl, mslam_ba_system* s)
     const BaDev& d = pl->dev;
     hipStream_t st = ctx->stream;
     auto dn = [&](void* dst, const void* src, size_t n) { return (dst && n) ? hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, st) : hipSuccess; };
-    HIP_TRY(ctx, dn(s->err, d.err, sizeof(double) * 2 * d.n_edges));
-    HIP_TRY(ctx, dn(s->chi2, d.chi2, sizeof(double) * d.n_edges));
-    HIP_TRY(ctx, dn(s->rho1, d.rho1, sizeof(double) * d.n_edges));
+    // err / chi2 / rho1 live in row order on the device (coalesced stores in ba_edges_k): they come back through a staging copy
+    // and are put into the caller's edge order here
+    const size_t E = (size_t)d.n_edges;
+    std::vector<double> h_err(s->err ? 2 * E : 0), h_chi((s->chi2 || s->rho1) ? E : 0);
+    HIP_TRY(ctx, dn(s->err ? h_err.data() : nullptr, d.err, sizeof(double) * 2 * E));
+    HIP_TRY(ctx, dn(h_chi.empty() ? nullptr : h_chi.data(), d.chi2, sizeof(double) * E));
     HIP_TRY(ctx, dn(s->Hpp, d.Hpp, sizeof(double) * 36 * d.n_free));
     HIP_TRY(ctx, dn(s->Hll, d.Hll, sizeof(double) * 9 * d.n_points));
     HIP_TRY(ctx, dn(s->Hpl_val, d.Hpl_val, sizeof(double) * 18 * d.nnzb));
     HIP_TRY(ctx, dn(s->b, d.b, sizeof(double) * (6 * d.n_free + 3 * d.n_points)));
     HIP_TRY(ctx, dn(&s->robust_chi2, d.robust_chi2, sizeof(double)));
     HIP_TRY(ctx, hipStreamSynchronize(st));
+    for (size_t k = 0; k < E; k++) {
+        const size_t e = (size_t)pl->h_edge_of_k[k];
+        if (s->err) { s->err[2 * e] = h_err[2 * k]; s->err[2 * e + 1] = h_err[2 * k + 1]; }
+        if (s->chi2) s->chi2[e] = h_chi[k];
+        if (s->rho1) {   // RobustKernelHuber::robustify's rho' (robust_kernel_impl.cpp:78-91), the same operations as the kernel's huber()
+            double r1 = 1.0;
+            if (pl->built_delta > 0 && !(h_chi[k] <= (double)pl->built_dsqr)) r1 = pl->built_delta / std::sqrt(h_chi[k]);
+            s->rho1[e] = r1;
+        }
+    }
     if (s->Hpl_rowptr) std::memcpy(s->Hpl_rowptr, pl->h_rowptr.data(), sizeof(int32_t) * (d.n_free + 1));
     if (s->Hpl_col && d.nnzb) std::memcpy(s->Hpl_col, pl->h_col.data(), sizeof(int32_t) * d.nnzb);
     s->n_free_poses = d.n_free; s->nnzb = d.nnzb;
