@@ -15,7 +15,7 @@
 // inside a row by point.  For a free row k IS the index of the edge's 6x3 Hpl block in the block-CSR (so the kernel
 // that evaluates an edge writes its block to consecutive memory), and every per-edge input is a streaming read:
 //   state    poses f64[n_poses][7] (t, q xyzw), points f64[n_points][3]
-//   rows     erowptr i32[R+1], row_pose i32[R]; rec i32x2[E] (point, original edge id), obs_k f64x2[E]
+//   rows     erowptr i32[R+1], row_pose i32[R]; rec i32[E] (the edge's point; its original id stays on the host), obs_k f64x2[E]
 //   by point pt_ptr i32[n_points+1], pt_k i32[E]   (row-order indices of a point's edges, ascending)
 //   ptside   f64[9][E]    per-edge point-side contributions (6 Hll + 3 b_l), plane-major: coalesced both ways
 // Kernels of one linearisation (no float atomics anywhere: every sum has a fixed shape, results are run-to-run identical):
@@ -60,7 +60,7 @@ struct BaDev {
     const int32_t* edge_pose; const double* info /* [E] in ROW order */; const double* intr;
     const int32_t* fidx;      // free index per pose or -1
     const int32_t* erowptr; const int32_t* row_pose;
-    const int2* rec;          // [E] {point, edge id} in row order
+    const int32_t* rec;       // [E] point of the edge, in row order
     const double2* obs_k;     // [E] observation in row order
     const int32_t* pt_ptr; const int32_t* pt_k;
     const int32_t* blk_row;   // [nnzb] free row of a block
@@ -180,9 +180,8 @@ void ba_edges_k(BaDev d)
 #pragma unroll
     for (int q = 0; q < 18; q++) Hb[q] = 0.0;
     if (live) {
-        const int2 rc = d.rec[k];
         const double2 ob = d.obs_k[k];
-        const int ip = rc.x;   // (rc.y, the caller's edge id, is only needed by the host: mslam_ba_plan_download)
+        const int ip = d.rec[k];   // (the caller's edge id is only needed by the host: mslam_ba_plan_download)
         const double* in = d.intr + 4 * jp;
         EdgeLin L;
         edge_eval(d.poses + 7 * jp, d.points[3 * ip], d.points[3 * ip + 1], d.points[3 * ip + 2], ob.x, ob.y, in[0], in[1], in[2], in[3], L);
@@ -827,7 +826,7 @@ int mslam_ba_plan_create(mslam_ctx* ctx, const mslam_ba_problem* p, mslam_ba_pla
     const size_t o_poses = reserve(sizeof(double) * 7 * NP), o_points = reserve(sizeof(double) * 3 * NL),
                  o_ep = reserve(sizeof(int32_t) * E), o_info = reserve(sizeof(double) * E), o_intr = reserve(sizeof(double) * 4 * NP),
                  o_fidx = reserve(sizeof(int32_t) * NP), o_erow = reserve(sizeof(int32_t) * (R + 1)), o_rowp = reserve(sizeof(int32_t) * R),
-                 o_rec = reserve(sizeof(int2) * E), o_obs = reserve(sizeof(double2) * E),
+                 o_rec = reserve(sizeof(int32_t) * E), o_obs = reserve(sizeof(double2) * E),
                  o_ptp = reserve(sizeof(int32_t) * (NL + 1)), o_ptk = reserve(sizeof(int32_t) * E),
                  o_col = reserve(sizeof(int32_t) * std::max(nnzb, 1)), o_brow = reserve(sizeof(int32_t) * std::max(nnzb, 1)),
                  o_err = reserve(sizeof(double) * 2 * E), o_chi = reserve(sizeof(double) * E),
@@ -861,12 +860,13 @@ int mslam_ba_plan_create(mslam_ctx* ctx, const mslam_ba_problem* p, mslam_ba_pla
     const double lam0 = 0.0;
     std::vector<double> info_k(E);
     pl->h_edge_of_k.resize(E);
-    for (int k = 0; k < E; k++) { pl->h_edge_of_k[(size_t)k] = rec[(size_t)k].y; info_k[(size_t)k] = p->info[rec[(size_t)k].y]; }
+    std::vector<int32_t> rec_pt(E);
+    for (int k = 0; k < E; k++) { pl->h_edge_of_k[(size_t)k] = rec[(size_t)k].y; info_k[(size_t)k] = p->info[rec[(size_t)k].y]; rec_pt[(size_t)k] = rec[(size_t)k].x; }
     std::vector<hipError_t> errs = {
         up(o_poses, p->poses, sizeof(double) * 7 * NP), up(o_points, p->points, sizeof(double) * 3 * NL),
         up(o_ep, p->edge_pose, sizeof(int32_t) * E), up(o_info, info_k.data(), sizeof(double) * E), up(o_intr, p->intr, sizeof(double) * 4 * NP),
         up(o_fidx, fidx.data(), sizeof(int32_t) * NP), up(o_erow, erowptr.data(), sizeof(int32_t) * (R + 1)),
-        up(o_rowp, row_pose.data(), sizeof(int32_t) * R), up(o_rec, rec.data(), sizeof(int2) * E), up(o_obs, obs_k.data(), sizeof(double2) * E),
+        up(o_rowp, row_pose.data(), sizeof(int32_t) * R), up(o_rec, rec_pt.data(), sizeof(int32_t) * E), up(o_obs, obs_k.data(), sizeof(double2) * E),
         up(o_ptp, pt_ptr.data(), sizeof(int32_t) * (NL + 1)), up(o_ptk, pt_k.data(), sizeof(int32_t) * E),
         up(o_col, col.data(), sizeof(int32_t) * nnzb), up(o_brow, blk_row.data(), sizeof(int32_t) * nnzb), up(o_lam, &lam0, sizeof(double)) };
     if (want_schur) {
@@ -889,7 +889,7 @@ int mslam_ba_plan_create(mslam_ctx* ctx, const mslam_ba_problem* p, mslam_ba_pla
     d.huber_delta = p->huber_delta; d.dsqr = (float)(p->huber_delta * p->huber_delta); // RobustKernelHuber: float dsqr
     d.poses = (double*)(base + o_poses); d.points = (double*)(base + o_points);
     d.edge_pose = (int32_t*)(base + o_ep); d.info = (double*)(base + o_info); d.intr = (double*)(base + o_intr); d.fidx = (int32_t*)(base + o_fidx);
-    d.erowptr = (int32_t*)(base + o_erow); d.row_pose = (int32_t*)(base + o_rowp); d.rec = (int2*)(base + o_rec); d.obs_k = (double2*)(base + o_obs);
+    d.erowptr = (int32_t*)(base + o_erow); d.row_pose = (int32_t*)(base + o_rowp); d.rec = (int32_t*)(base + o_rec); d.obs_k = (double2*)(base + o_obs);
     d.pt_ptr = (int32_t*)(base + o_ptp); d.pt_k = (int32_t*)(base + o_ptk); d.blk_row = (int32_t*)(base + o_brow);
     d.err = (double*)(base + o_err); d.chi2 = (double*)(base + o_chi); d.rho1 = nullptr;   // (the Huber weight is a function of chi2: not streamed out per edge)
     d.Hpp = (double*)(base + o_hpp); d.Hll = (double*)(base + o_hll); d.Hpl_val = (double*)(base + o_hpl); d.b = (double*)(base + o_b);
