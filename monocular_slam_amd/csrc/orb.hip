@@ -1044,7 +1044,7 @@ constexpr int DP_R = 21;               // raw patch radius: 18 (pattern reach) +
 constexpr int DP_N = 2 * DP_R + 1;     // 43
 constexpr int DP_PITCH = 48;           // LDS bytes per raw row: three 16-byte LDS-DMA chunks (45 bytes + misalignment)
 constexpr int DH_RP = 22, DH_CG = 10;  // row pass: 22 row pairs x 10 groups of 4 columns (44 x 40 >= 43 x 37)
-constexpr int HT_DW = 23;              // dwords per column of the transposed row-pass result (46 u16 rows; odd)
+constexpr int HT_DW = 22;              // dwords per column of the transposed row-pass result (44 u16 rows)
 constexpr int DESC_WAVES = 4;
 
 __device__ __forceinline__ float fast_atan2_deg(float y, float x)
