@@ -17,13 +17,13 @@
 //   state    poses f64[n_poses][7] (t, q xyzw), points f64[n_points][3]
 //   rows     erowptr i32[R+1], row_pose i32[R]; rec i32[E] (the edge's point; its original id stays on the host), obs_k f64x2[E]
 //   by point pt_ptr i32[n_points+1], pt_k i32[E]   (row-order indices of a point's edges, ascending)
-//   ptside   f64[9][E]    per-edge point-side contributions (6 Hll + 3 b_l), plane-major: coalesced both ways
+//   kpose    i32[E]       pose of the edge at row-order position k
 // Kernels of one linearisation (no float atomics anywhere: every sum has a fixed shape, results are run-to-run identical):
-//   ba_edges_k   grid (chunk, row), one lane per edge: residual, Huber weight, Jacobians ONCE per edge; err/chi2/rho1 by
-//                edge id; the point-side terms into ptside; for free rows the 6x3 block goes through an LDS transpose and
+//   ba_edges_k   grid (chunk, row), one lane per edge: residual, Huber weight, Jacobians; err / chi2 in row order;
+//                for free rows the 6x3 block goes through an LDS transpose and
 //                leaves as 16-byte stores of consecutive memory, and the 27 pose-side sums are reduced by a wavefront
 //                butterfly + 4 wavefront partials into the chunk's partial
-//   ba_points_k  one lane per point: adds its edges' ptside rows in row order -> Hll, b_l, robust chi2 of the point
+//   ba_points_k  one lane per point: evaluates its edges (row order) a second time -> Hll, b_l, robust chi2 of the point
 //   ba_final_k   adds the chunk partials per pose in chunk order, reduces the robust chi2
 // Schur complement (tiles of at most SCHUR_TP consecutive points, ending at the seams of the pose graph; a tile's pose list and its dense point x local-pose block table
 // are plan data, O(points x poses-per-tile) instead of the dense poses x points table):
@@ -65,7 +65,7 @@ struct BaDev {
     const int32_t* pt_ptr; const int32_t* pt_k;
     const int32_t* blk_row;   // [nnzb] free row of a block
     double* err; double* chi2; double* rho1; double* Hpp; double* Hll; double* Hpl_val; double* b;
-    double* ptside;           // [9][E]
+    const int32_t* kpose;     // [E] pose of the edge at row-order position k (ba_points_k evaluates a point's edges itself)
     double* pt_rho;           // [n_points] robust chi2 per point
     double* chi_part;         // [ceil(n_points / 4096)] slice sums of pt_rho (large problems)
     double* pose_part;        // [n_free][n_chunks_max][27]
@@ -193,13 +193,7 @@ void ba_edges_k(BaDev d)
         const double wom = rho1 * om;
         const double r0 = -(om * L.e0) * rho1, r1 = -(om * L.e1) * rho1;
         const double* A = L.A;
-        const size_t E = (size_t)d.n_edges;
-        double* ps = d.ptside + k;
-        ps[0] = wom * (A[0] * A[0] + A[3] * A[3]);     ps[E] = wom * (A[0] * A[1] + A[3] * A[4]);
-        ps[2 * E] = wom * (A[0] * A[2] + A[3] * A[5]); ps[3 * E] = wom * (A[1] * A[1] + A[4] * A[4]);
-        ps[4 * E] = wom * (A[1] * A[2] + A[4] * A[5]); ps[5 * E] = wom * (A[2] * A[2] + A[5] * A[5]);
-        ps[6 * E] = A[0] * r0 + A[3] * r1; ps[7 * E] = A[1] * r0 + A[4] * r1; ps[8 * E] = A[2] * r0 + A[5] * r1;
-        (void)rho0;   // (the point's robust chi2 is re-formed from chi2 in ba_points_k: a tenth plane of 8 bytes per edge saved)
+        (void)rho0;   // (the point side -- Hll, b_l, the robust chi2 -- is formed by ba_points_k from the same inputs: no per-edge scratch)
         if (f >= 0) {
 #pragma unroll
             for (int a = 0; a < 6; a++) { // B^T (w Omega) A, row-major 6x3
@@ -238,19 +232,35 @@ void ba_edges_k(BaDev d)
 __global__ __launch_bounds__(256)
 void ba_points_k(BaDev d)
 {
+    // One lane per point: its edges (ascending row order: a fixed summation order) are evaluated HERE a second time -- residual,
+    // Huber weight, the 2x3 point Jacobian -- instead of being read back from a per-edge scratch written by ba_edges_k.  The
+    // linearisation is HBM-bound (ba_edges_k streams 150+ bytes of blocks per edge): 72 bytes written and 72 read per edge cost
+    // more than the ~250 f64 instructions of a second evaluation, whose inputs (pose, intrinsics: cache-resident; observation,
+    // information: 24 streamed bytes) are small.
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= d.n_points) return;
     double acc[10];
 #pragma unroll
     for (int q = 0; q < 10; q++) acc[q] = 0.0;
-    const size_t E = (size_t)d.n_edges;
-    for (int kk = d.pt_ptr[i]; kk < d.pt_ptr[i + 1]; kk++) {   // ascending row order: a fixed summation order
+    const double X0 = d.points[3 * (size_t)i], X1 = d.points[3 * (size_t)i + 1], X2 = d.points[3 * (size_t)i + 2];
+    for (int kk = d.pt_ptr[i]; kk < d.pt_ptr[i + 1]; kk++) {
         const int k = d.pt_k[kk];
-        const double* ps = d.ptside + k;
-#pragma unroll
-        for (int q = 0; q < 9; q++) acc[q] += ps[q * E];
-        double rho0, rho1;   // the edge's robust chi2 from its chi2 (row order, as ba_edges_k left it): the same operations as there
-        huber(d.chi2[k], d.huber_delta, d.dsqr, rho0, rho1);
+        const int jp = d.kpose[k];
+        const double2 ob = d.obs_k[k];
+        const double* in = d.intr + 4 * jp;
+        EdgeLin L;
+        edge_eval(d.poses + 7 * jp, X0, X1, X2, ob.x, ob.y, in[0], in[1], in[2], in[3], L);
+        const double om = d.info[k];
+        const double chi2 = L.e0 * (om * L.e0) + L.e1 * (om * L.e1);
+        double rho0, rho1;
+        huber(chi2, d.huber_delta, d.dsqr, rho0, rho1);
+        const double wom = rho1 * om;
+        const double r0 = -(om * L.e0) * rho1, r1 = -(om * L.e1) * rho1;
+        const double* A = L.A;
+        acc[0] += wom * (A[0] * A[0] + A[3] * A[3]); acc[1] += wom * (A[0] * A[1] + A[3] * A[4]);
+        acc[2] += wom * (A[0] * A[2] + A[3] * A[5]); acc[3] += wom * (A[1] * A[1] + A[4] * A[4]);
+        acc[4] += wom * (A[1] * A[2] + A[4] * A[5]); acc[5] += wom * (A[2] * A[2] + A[5] * A[5]);
+        acc[6] += A[0] * r0 + A[3] * r1; acc[7] += A[1] * r0 + A[4] * r1; acc[8] += A[2] * r0 + A[5] * r1;
         acc[9] += rho0;
     }
     double* H = d.Hll + (size_t)i * 9;
@@ -832,7 +842,7 @@ int mslam_ba_plan_create(mslam_ctx* ctx, const mslam_ba_problem* p, mslam_ba_pla
                  o_err = reserve(sizeof(double) * 2 * E), o_chi = reserve(sizeof(double) * E),
                  o_hpp = reserve(sizeof(double) * 36 * std::max(nf, 1)), o_hll = reserve(sizeof(double) * 9 * NL),
                  o_hpl = reserve(sizeof(double) * 18 * std::max(nnzb, 1)), o_b = reserve(sizeof(double) * (6 * nf + 3 * NL)),
-                 o_pts = reserve(sizeof(double) * 9 * (size_t)E),
+                 o_kpose = reserve(sizeof(int32_t) * (size_t)E),
                  o_ptr = reserve(sizeof(double) * NL), o_chp = reserve(sizeof(double) * ((size_t)NL / CHI_SLICE + 1)),
                  o_pp = reserve(sizeof(double) * 27 * (size_t)std::max(nf, 1) * n_chunks_max), o_rc = reserve(sizeof(double)),
                  o_lam = reserve(sizeof(double));
@@ -860,13 +870,15 @@ int mslam_ba_plan_create(mslam_ctx* ctx, const mslam_ba_problem* p, mslam_ba_pla
     const double lam0 = 0.0;
     std::vector<double> info_k(E);
     pl->h_edge_of_k.resize(E);
-    std::vector<int32_t> rec_pt(E);
+    std::vector<int32_t> rec_pt(E), kpose(E);
+    for (int r = 0; r < R; r++)
+        for (int k = erowptr[r]; k < erowptr[r + 1]; k++) kpose[(size_t)k] = row_pose[(size_t)r];
     for (int k = 0; k < E; k++) { pl->h_edge_of_k[(size_t)k] = rec[(size_t)k].y; info_k[(size_t)k] = p->info[rec[(size_t)k].y]; rec_pt[(size_t)k] = rec[(size_t)k].x; }
     std::vector<hipError_t> errs = {
         up(o_poses, p->poses, sizeof(double) * 7 * NP), up(o_points, p->points, sizeof(double) * 3 * NL),
         up(o_ep, p->edge_pose, sizeof(int32_t) * E), up(o_info, info_k.data(), sizeof(double) * E), up(o_intr, p->intr, sizeof(double) * 4 * NP),
         up(o_fidx, fidx.data(), sizeof(int32_t) * NP), up(o_erow, erowptr.data(), sizeof(int32_t) * (R + 1)),
-        up(o_rowp, row_pose.data(), sizeof(int32_t) * R), up(o_rec, rec_pt.data(), sizeof(int32_t) * E), up(o_obs, obs_k.data(), sizeof(double2) * E),
+        up(o_rowp, row_pose.data(), sizeof(int32_t) * R), up(o_rec, rec_pt.data(), sizeof(int32_t) * E), up(o_kpose, kpose.data(), sizeof(int32_t) * E), up(o_obs, obs_k.data(), sizeof(double2) * E),
         up(o_ptp, pt_ptr.data(), sizeof(int32_t) * (NL + 1)), up(o_ptk, pt_k.data(), sizeof(int32_t) * E),
         up(o_col, col.data(), sizeof(int32_t) * nnzb), up(o_brow, blk_row.data(), sizeof(int32_t) * nnzb), up(o_lam, &lam0, sizeof(double)) };
     if (want_schur) {
@@ -893,7 +905,7 @@ int mslam_ba_plan_create(mslam_ctx* ctx, const mslam_ba_problem* p, mslam_ba_pla
     d.pt_ptr = (int32_t*)(base + o_ptp); d.pt_k = (int32_t*)(base + o_ptk); d.blk_row = (int32_t*)(base + o_brow);
     d.err = (double*)(base + o_err); d.chi2 = (double*)(base + o_chi); d.rho1 = nullptr;   // (the Huber weight is a function of chi2: not streamed out per edge)
     d.Hpp = (double*)(base + o_hpp); d.Hll = (double*)(base + o_hll); d.Hpl_val = (double*)(base + o_hpl); d.b = (double*)(base + o_b);
-    d.ptside = (double*)(base + o_pts);
+    d.kpose = (int32_t*)(base + o_kpose);
     d.pt_rho = (double*)(base + o_ptr); d.chi_part = (double*)(base + o_chp); d.pose_part = (double*)(base + o_pp); d.robust_chi2 = (double*)(base + o_rc);
     pl->d_poses = (double*)(base + o_poses); pl->d_points = (double*)(base + o_points);
     pl->d_rowptr = (int32_t*)(base + o_erow); pl->d_col = (int32_t*)(base + o_col);   // free rows come first: erowptr[0..nf] IS the block-CSR row pointer
