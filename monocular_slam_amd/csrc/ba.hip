@@ -47,7 +47,9 @@
 
 namespace {
 
-constexpr int EDGE_CHUNK = 256;    // edges per ba_edges_k workgroup
+constexpr int EDGE_THREADS = 256;  // lanes of a ba_edges_k workgroup
+constexpr int EDGE_EPL = 2;        // edges per lane
+constexpr int EDGE_CHUNK = EDGE_THREADS * EDGE_EPL;    // edges per ba_edges_k workgroup
 constexpr int T_PITCH = 258;       // LDS plane pitch (doubles) of the block transpose: 258 = 2 (mod 32) spreads the planes over banks
 constexpr int SCHUR_TP = 64;       // points per Schur tile
 constexpr int SCHUR_LMAX = 64;     // local poses per tile beyond which the device Schur path is not offered
@@ -161,7 +163,7 @@ __device__ __forceinline__ double chunk_reduce(double (&v)[NV], double* s_red /*
     return t;
 }
 
-__global__ __launch_bounds__(EDGE_CHUNK)
+__global__ __launch_bounds__(EDGE_THREADS)
 void ba_edges_k(BaDev d)
 {
     const int r = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
@@ -170,13 +172,19 @@ void ba_edges_k(BaDev d)
     if (kb >= k1) return; // whole workgroup out of range
     __shared__ double s_t[18 * T_PITCH];
     __shared__ double s_red[27 * 4];
-    const int k = kb + tid;
     const int jp = d.row_pose[r];          // the whole row shares one pose: uniform (scalar) loads
     const int f = d.fidx[jp];
-    const bool live = k < k1;
-    double v[27], Hb[18];
+    double v[27];
 #pragma unroll
     for (int q = 0; q < 27; q++) v[q] = 0.0;
+    // EDGE_EPL edges per lane, one after the other: the 27 pose-side sums stay in the lane's registers across them, so the
+    // cross-lane reduction at the end (27 values x 6 butterfly steps) is paid once per EDGE_EPL edges
+    for (int sub = 0; sub < EDGE_EPL; sub++) {
+    const int kbs = kb + sub * EDGE_THREADS;
+    if (kbs >= k1) break;                  // workgroup-uniform
+    const int k = kbs + tid;
+    const bool live = k < k1;
+    double Hb[18];
 #pragma unroll
     for (int q = 0; q < 18; q++) Hb[q] = 0.0;
     if (live) {
@@ -206,25 +214,28 @@ void ba_edges_k(BaDev d)
 #pragma unroll
             for (int a = 0; a < 6; a++)
 #pragma unroll
-                for (int c = a; c < 6; c++) v[q++] = wom * (L.B[a] * L.B[c] + L.B[6 + a] * L.B[6 + c]);
+                for (int c = a; c < 6; c++) v[q++] += wom * (L.B[a] * L.B[c] + L.B[6 + a] * L.B[6 + c]);
 #pragma unroll
-            for (int a = 0; a < 6; a++) v[21 + a] = L.B[a] * r0 + L.B[6 + a] * r1;
+            for (int a = 0; a < 6; a++) v[21 + a] += L.B[a] * r0 + L.B[6 + a] * r1;
         }
     }
-    if (f < 0) return; // fixed pose (uniform): no Hpl row, no pose block
-    // the workgroup's blocks are consecutive in Hpl_val: transpose through LDS ([value][lane] planes) and write 16-byte
+    if (f < 0) continue; // fixed pose (uniform): no Hpl row, no pose block
+    // the sub-chunk's blocks are consecutive in Hpl_val: transpose through LDS ([value][lane] planes) and write 16-byte
     // pieces of consecutive memory instead of 18 stride-144 doubles per lane
+    if (sub) __syncthreads();   // the previous sub-chunk's planes have been read
 #pragma unroll
     for (int q = 0; q < 18; q++) s_t[q * T_PITCH + tid] = Hb[q];
     __syncthreads();
     {
-        const int n_live = min(EDGE_CHUNK, k1 - kb);
-        double2* out = reinterpret_cast<double2*>(d.Hpl_val + (size_t)kb * 18);   // (kb * 144) bytes: 16-byte aligned
-        for (int c = tid; c < n_live * 9; c += EDGE_CHUNK) {
+        const int n_live = min(EDGE_THREADS, k1 - kbs);
+        double2* out = reinterpret_cast<double2*>(d.Hpl_val + (size_t)kbs * 18);   // (kbs * 144) bytes: 16-byte aligned
+        for (int c = tid; c < n_live * 9; c += EDGE_THREADS) {
             const int kl = c / 9, q = 2 * (c - 9 * kl);
             out[c] = make_double2(s_t[q * T_PITCH + kl], s_t[(q + 1) * T_PITCH + kl]);
         }
     }
+    }   // sub
+    if (f < 0) return;
     const double t = chunk_reduce<27>(v, s_red, tid);
     if (tid < 27) d.pose_part[((size_t)f * d.n_chunks_max + chunk) * 27 + tid] = t;
 }
@@ -1023,7 +1034,7 @@ int mslam_ba_plan_build_dev(mslam_ba_plan* pl)
     MSLAM_TRY(ctx_set_device(ctx));
     const BaDev& d = pl->dev;
     pl->built_delta = d.huber_delta; pl->built_dsqr = d.dsqr;
-    LAUNCH(ctx, K_BA_POSES, ba_edges_k, dim3(d.n_chunks_max, d.n_rows), dim3(EDGE_CHUNK), 0, d);
+    LAUNCH(ctx, K_BA_POSES, ba_edges_k, dim3(d.n_chunks_max, d.n_rows), dim3(EDGE_THREADS), 0, d);
     LAUNCH(ctx, K_BA_POINTS, ba_points_k, dim3((d.n_points + 255) / 256), dim3(256), 0, d);
     if (d.n_points <= 2 * CHI_SLICE && d.n_free * 27 <= 4096) {
         LAUNCH(ctx, K_BA_FINAL, ba_final_k, dim3(1), dim3(256), 0, d, 0);
