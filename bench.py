@@ -513,7 +513,7 @@ def ba_roofline(api, ctx, windows: int = 32, reps: int = 20) -> dict:
             "whole_build": {"kernels_ms": {k: round(v, 5) for k, v in prof.items()}, "ms": total, "achieved": alg / (total * 1e-3) / 1e9,
                             "frac": alg / (total * 1e-3) / 1e9 / HBM_PEAK_GBS, "window_builds_per_s": windows / (total * 1e-3)},
             "workload": "BASELINE configs[3]: BA residual/Jacobian build, 10 keyframes x 5000 map points per window, J^T J blocks to block-CSR",
-            "note": "separate leg after the timed region, one stream, kernels alone on the chip; counter traffic of this kernel: profiles/r03_pmc_summary_ba_probe.json"}
+            "note": "separate leg after the timed region, one stream, kernels alone on the chip; `frac` prices the dominant kernel with SURVEY 8d's 216 B per edge (the figure of the whole build: the kernel itself moves 195 B per edge of counter traffic, profiles/r03_pmc_summary_ba_probe.json), `whole_build.frac` the same bytes over all three kernels of the build"}
 
 
 def roofline_blocks(kern, kern_x, nprof, SB, NS, value, world) -> dict:
