@@ -145,16 +145,24 @@ __device__ __forceinline__ void huber(double chi2, double delta, float dsqr, dou
     }
 }
 
-// fixed-shape workgroup sum of NV values per lane: xor butterfly inside each wavefront (registers), then the 4 wavefront
+// fixed-shape workgroup sum of NV values per lane: a DPP scan inside each wavefront (registers), then the 4 wavefront
 // sums in index order by thread q < NV; the result of value q is returned to thread q (others get garbage)
 template <int NV>
 __device__ __forceinline__ double chunk_reduce(double (&v)[NV], double* s_red /* NV * 4 */, int tid)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1)
-#pragma unroll
-        for (int q = 0; q < NV; q++) v[q] += __shfl_xor(v[q], o);
-    if ((tid & 63) == 0)
+    // wavefront sums by DPP moves (the two halves of a double travel as two v_mov_b32_dpp): an inclusive scan inside each row of
+    // 16 lanes (row_shr 1, 2, 4, 8; +0.0 shifted in), row totals handed on by row_bcast:15 / :31, the total in lane 63 -- no LDS
+    // round trips (the xor butterfly of __shfl_xor was 2 ds_bpermute per value and step: the kernel's limiter)
+#define BA_DPP_ADD(ctrl, rmask, bc)                                                                                     \
+    _Pragma("unroll") for (int q = 0; q < NV; q++) {                                                                    \
+        const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v[q]), ctrl, rmask, 0xf, bc);                       \
+        const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v[q]), ctrl, rmask, 0xf, bc);                       \
+        v[q] += __hiloint2double(hi, lo);                                                                               \
+    }
+    BA_DPP_ADD(0x111, 0xf, true) BA_DPP_ADD(0x112, 0xf, true) BA_DPP_ADD(0x114, 0xf, true) BA_DPP_ADD(0x118, 0xf, true)
+    BA_DPP_ADD(0x142, 0xa, false) BA_DPP_ADD(0x143, 0xc, false)
+#undef BA_DPP_ADD
+    if ((tid & 63) == 63)
 #pragma unroll
         for (int q = 0; q < NV; q++) s_red[q * 4 + (tid >> 6)] = v[q];
     __syncthreads();
